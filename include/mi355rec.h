@@ -1,0 +1,247 @@
+/*
+ * mi355rec.h - C ABI of libmi355rec.so (gfx950 / MI355X).
+ *
+ * The reference (wuchaochen/recommendation) has no native boundary: its hot path is the
+ * Python class API of recommendation/code/r_model.py, whose arithmetic executes inside
+ * TensorFlow.  This header is the boundary that replaces those TensorFlow op calls.  Each
+ * entry point cites the reference lines whose computation it takes over.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  Every pointer is DEVICE memory owned by the
+ *     caller unless the comment says "host".
+ *   - Every function returns 0 on success or a negative MI_ERR_* code; mi_last_error()
+ *     gives a host string for the calling thread's last failure.
+ *   - Work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises
+ *     the host.  No entry point allocates device memory: scratch comes in through a
+ *     caller-provided workspace whose size a *_workspace_bytes() call reports.
+ *   - Bad ids are REPORTED, never clamped: kernels OR bits into the caller's device
+ *     error word `err` (MI_IDERR_*), the entry skipped; the caller reads it back when it
+ *     wants the check (the reference raises InvalidArgumentError at session.run).
+ *   - Re-entrant across distinct streams and workspaces; no global state.
+ */
+#ifndef MI355REC_H
+#define MI355REC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_ERR_INVALID_ARG (-1) /* shape / alignment / enum check failed on the host   */
+#define MI_ERR_HIP (-2)         /* a HIP runtime call or kernel launch failed           */
+#define MI_ERR_WORKSPACE (-3)   /* workspace too small                                  */
+#define MI_ERR_UNSUPPORTED (-4) /* valid request outside what the kernels are built for */
+
+/* bits a kernel may OR into the device error word */
+#define MI_IDERR_RANGE 1    /* id >= rows of its table (or negative where not allowed)    */
+#define MI_IDERR_ORDER 2    /* ids of one bag not strictly increasing (repeat / disorder) */
+#define MI_IDERR_INTERNAL 4 /* a bounded device-side wait ran out (never expected)        */
+
+/* flags for id validation */
+#define MI_CHECK_RANGE 1     /* id must be < rows                                         */
+#define MI_CHECK_INCREASING 2 /* ids of a bag strictly increasing (tf.sparse_to_dense)    */
+#define MI_CHECK_NONNEG 4    /* a negative id is an error instead of a padding entry      */
+
+#define MI_POOL_SUM 0
+#define MI_POOL_MEAN 1
+
+#define MI_DT_F32 0
+#define MI_DT_BF16 1
+
+const char* mi_version(void);
+const char* mi_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Bags.  A "bag" is the list of ids one sample feeds to one table.  n_bags = B * T and
+ * bag i belongs to sample i / T and table i % T.  Ids are table-local, int32 or int64
+ * (idx_bits).  Layout: either fixed width (offsets == NULL, bag i = indices[i*bag_len ..
+ * (i+1)*bag_len)) or CSR (offsets[n_bags+1], int64).  A negative id is a padding entry.
+ * All T tables share `dim` and live in ONE row-major fp32 array `weights[total_rows][dim]`;
+ * table t owns rows [table_offsets[t], table_offsets[t+1]) (int64, device, T+1 entries).
+ * ---------------------------------------------------------------------------------- */
+
+/* Embedding gather + sum/mean pooling, all tables in one launch.
+ * out[(i/T)*out_ld + (i%T)*dim + d] = pool_j weights[table_offsets[i%T] + id_j][d].
+ * Replaces one-hot/n-hot materialisation followed by the first tf.layers.dense MatMul:
+ * r_model.py:60-66 (one-hot), :68-80 (n-hot == sum pooling), :82-96 (padding id),
+ * :53-54 (the MatMul and BiasAdd the dense matrix feeds).  `bias` (T*dim floats, added to
+ * every pooled row after pooling) may be NULL. */
+int mi_embag_fwd(const float* weights, const int64_t* table_offsets, int T, int dim,
+                 const void* indices, int idx_bits, const int64_t* offsets, int bag_len,
+                 int64_t n_bags, int pool_mode, int check_flags, const float* bias,
+                 void* out, int out_dtype, int64_t out_ld, int32_t* err, void* stream);
+
+/* Dense one-hot / n-hot matrix exactly as the reference materialises it (kept for callers
+ * that consume the dense matrix itself, e.g. the label tensor of the loss):
+ * out[b][c] = 1.0 if c is among the non-negative ids of bag b else 0.0; ids validated with
+ * check_flags against `size`.  r_model.py:60-96. */
+int mi_onehot_dense(const void* indices, int idx_bits, int bag_len, int64_t n_bags, int size,
+                    int check_flags, float* out, int32_t* err, void* stream);
+
+/* Validation only (tf.sparse_to_dense validate_indices=True semantics, r_model.py:65,76,90);
+ * table t has table_offsets[t+1]-table_offsets[t] rows. */
+int mi_validate_ids(const int64_t* table_offsets, int T, const void* indices, int idx_bits,
+                    const int64_t* offsets, int bag_len, int64_t n_bags, int check_flags,
+                    int32_t* err, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Sparse backward, step 1: deterministic sort by (table,row).
+ * Entry p (position in `indices`) gets key = table_offsets[t] + id (a global row, uint32;
+ * total_rows must be < 2^32-1); padding and invalid entries sort to the end and are not
+ * counted.  Stable LSD radix sort, so equal rows keep ascending p.  Outputs:
+ *   sorted_rows[n]  uint32  global row of each sorted entry (first n_valid meaningful)
+ *   perm[n]         int32   original position p of each sorted entry
+ *   unique_rows[n]  uint32  distinct rows, ascending (first n_unique meaningful)
+ *   seg_offsets[n+1] int32  start of each distinct row's run in sorted_rows; entry
+ *                           [n_unique] = n_valid
+ *   counts[2]       int32   {n_unique, n_valid}
+ * These are the bit-exact artefacts (== numpy stable argsort / unique).
+ * No reference counterpart: TensorFlow's MatMul gradient builds the dense [V,D] gradient
+ * (model_trainer.py:157-158); this is its sparse equivalent.
+ * ---------------------------------------------------------------------------------- */
+size_t mi_embag_bwd_workspace_bytes(int64_t n_entries);
+int mi_embag_bwd_prepare(const int64_t* table_offsets, int T, int64_t total_rows,
+                         const void* indices, int idx_bits, const int64_t* offsets, int bag_len,
+                         int64_t n_bags, int64_t n_entries,
+                         uint32_t* sorted_rows, int32_t* perm, uint32_t* unique_rows,
+                         int32_t* seg_offsets, int32_t* counts,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Generic stable key/value radix sort used by the above (exported for tests).
+ * keys/vals are overwritten with the sorted result; key_bits = number of low bits that
+ * differ (passes = ceil(key_bits/8)). */
+int mi_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int key_bits,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Sparse backward, step 2: segmented reduction of the bag gradients + optimizer.
+ * grad_out[(i/T)*grad_ld + (i%T)*dim + d] is dL/d(pooled output of bag i); an entry of a
+ * mean-pooled bag receives it divided by the bag's count of non-padding ids.
+ * The gradient of distinct row r is the sum over its run, taken in a fixed order
+ * (deterministic, no atomics).  `long_list` is int32 scratch of n_entries+1 ints.
+ * ---------------------------------------------------------------------------------- */
+typedef struct mi_bwd_plan {
+  const uint32_t* sorted_rows;
+  const int32_t* perm;
+  const uint32_t* unique_rows;
+  const int32_t* seg_offsets;
+  const int32_t* counts;  /* {n_unique, n_valid} on device */
+  int64_t n_entries;      /* capacity (upper bound of n_valid) */
+  int64_t n_bags;
+  const int64_t* offsets; /* CSR offsets or NULL */
+  int bag_len;
+  int T;
+  int pool_mode;
+  int32_t* long_list; /* scratch, n_entries + 1 ints */
+  /* needed for MI_POOL_MEAN only (the bag's count of valid ids); may be NULL for sum */
+  const void* indices;
+  int idx_bits;
+  const int64_t* table_offsets;
+} mi_bwd_plan;
+
+/* Dense gradient dW[total_rows][dim] (zero on untouched rows): what TensorFlow's MatMul
+ * gradient X^T dY yields for a one-hot X (model_trainer.py:157-158). */
+int mi_embag_bwd_dense_grad(const mi_bwd_plan* plan, const float* grad_out, int64_t grad_ld,
+                            int dim, int64_t total_rows, float* dW, void* stream);
+
+/* Fused sparse updates: only rows that appear in the batch are read and written. */
+int mi_embag_bwd_apply_sgd(const mi_bwd_plan* plan, const float* grad_out, int64_t grad_ld,
+                           int dim, float* weights, float lr, void* stream);
+/* state[total_rows] fp32, one accumulator per row: s += mean_d(g^2); w -= lr*g/(sqrt(s)+eps) */
+int mi_embag_bwd_apply_adagrad_rowwise(const mi_bwd_plan* plan, const float* grad_out,
+                                       int64_t grad_ld, int dim, float* weights, float* state,
+                                       float lr, float eps, void* stream);
+/* Lazy (sparse) Adam in TensorFlow's form; lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the
+ * caller: m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2; w -= lr_t*m/(sqrt(v)+eps)  (touched rows only). */
+int mi_embag_bwd_apply_adam_tf(const mi_bwd_plan* plan, const float* grad_out, int64_t grad_ld,
+                               int dim, float* weights, float* m, float* v, float lr_t,
+                               float beta1, float beta2, float eps, void* stream);
+/* Dense Adam in TensorFlow's form over ALL total_rows rows, gradient zero on untouched rows:
+ * reproduces tf.train.AdamOptimizer on a first-layer kernel (model_trainer.py:157-158)
+ * without materialising dW. */
+int mi_embag_bwd_apply_adam_dense_tf(const mi_bwd_plan* plan, const float* grad_out,
+                                     int64_t grad_ld, int dim, int64_t total_rows, float* weights,
+                                     float* m, float* v, float lr_t, float beta1, float beta2,
+                                     float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Small dense fp32 layers of the colour model (tf.layers.dense, activation=None):
+ * y = x W + b, r_model.py:52-58.  x[B][K] (row stride x_ld), W[K][N], b[N], y[B][N] (y_ld).
+ * ---------------------------------------------------------------------------------- */
+int mi_linear_fwd(const float* x, int64_t x_ld, const float* W, const float* b, float* y,
+                  int64_t y_ld, int64_t B, int K, int N, void* stream);
+/* dx = dy W^T (may be NULL), dW = x^T dy, db = sum_b dy; deterministic two-stage sums.
+ * workspace: mi_linear_bwd_workspace_bytes(B,K,N). */
+size_t mi_linear_bwd_workspace_bytes(int64_t B, int K, int N);
+int mi_linear_bwd(const float* x, int64_t x_ld, const float* W, const float* dy, int64_t dy_ld,
+                  float* dx, int64_t dx_ld, float* dW, float* db, int64_t B, int K, int N,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* Heads of the colour model in one launch per row block:
+ *   probs = softmax(logits)                               r_model.py:99,104,109
+ *   top_idx/top_val = top_k(probs, k): descending, ties -> lower index   r_model.py:100,105
+ *   loss_rows[b] = -sum_c labels[b][c]*log_softmax(logits)[b][c]         r_model.py:116-118
+ *   dlogits = (probs - labels) * grad_scale   (TensorFlow's fused xent gradient; an
+ *             all-zero label row still gets probs*grad_scale)
+ *   hit_rows[b] = #{j : label_ids[b] == top_idx[b][j]}                   r_model.py:132-138
+ * Any output pointer may be NULL; labels (dense [B][N]) may be NULL when loss_rows and
+ * dlogits are NULL; label_ids (int32 [B]) may be NULL when hit_rows is NULL. N <= 4096. */
+int mi_softmax_heads(const float* logits, int64_t ld, int64_t B, int N, int k,
+                     const float* labels, const int32_t* label_ids, float grad_scale,
+                     float* probs, int32_t* top_idx, float* top_val, float* loss_rows,
+                     float* dlogits, float* hit_rows, void* stream);
+
+/* hit_rows[b] = #{j < k : labels[b] == preds[b][j]} as float (r_model.py:132-138, the
+ * tile/reshape/transpose/equal/matmul-with-ones construction). */
+int mi_hit_rows(const int32_t* labels, const int32_t* preds, int64_t B, int k, float* hit_rows,
+                void* stream);
+
+/* out[n] = sum_b x[b][n] for n < N (fixed order): the BiasAdd gradient. */
+int mi_colsum(const float* x, int64_t ld, int64_t B, int N, float* out, void* stream);
+
+/* out[0] = scale * sum_i x[i], summed in a fixed order (reduce_mean r_model.py:117,
+ * reduce_sum / batch_size r_model.py:138-139). */
+int mi_reduce_sum(const float* x, int64_t n, float scale, float* out, void* stream);
+
+/* tf.train.AdamOptimizer applied densely to a flat fp32 buffer (model_trainer.py:157-158):
+ * m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2; p -= lr_t*m/(sqrt(v)+eps). */
+int mi_adam_tf_dense(float* p, float* m, float* v, const float* g, int64_t n, float lr_t,
+                     float beta1, float beta2, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * FM (not in the reference; extension named by the benchmark definition).
+ * logit[b] = bias + sum_f w1[row(b,f)] + sum_j wd[j]*dense[b][j]
+ *            + 0.5 * sum_k ( (sum_f V[row(b,f)][k])^2 - sum_f V[row(b,f)][k]^2 )
+ * one id per field: ids[B][T].  Also emits S[b][k] = sum_f V[row][k] (kept for backward),
+ * and, when labels != NULL, BCE-with-logits loss rows and g[b] = (sigmoid(logit)-y)*gscale.
+ * ---------------------------------------------------------------------------------- */
+int mi_fm_fwd(const float* V, const float* w1, const int64_t* table_offsets, int T, int dim,
+              const void* ids, int idx_bits, int64_t B, const float* dense, int n_dense,
+              const float* wd, const float* bias, const float* labels, float gscale,
+              float* logit, float* S, float* loss_rows, float* g, int32_t* err, void* stream);
+
+#define MI_OPT_SGD 0
+#define MI_OPT_ADAGRAD_ROWWISE 1
+#define MI_OPT_ADAM_TF 2
+
+/* FM backward fused with the sparse update of V and w1.  For distinct row r with run
+ * {b_i}: dV[r] = sum_i g[b_i]*S[b_i] - V[r]*sum_i g[b_i];  dw1[r] = sum_i g[b_i].
+ * plan comes from mi_embag_bwd_prepare on ids (bag_len 1).  State buffers by optimizer:
+ *   SGD: none;  ADAGRAD_ROWWISE: st0 = accV[total_rows], st1 = accw1[total_rows];
+ *   ADAM_TF: st0 = mV, st1 = vV ([total_rows][dim]), st2 = mw1, st3 = vw1 ([total_rows]). */
+int mi_fm_bwd_apply(const mi_bwd_plan* plan, const float* g, const float* S, int dim, float* V,
+                    float* w1, int opt, float* st0, float* st1, float* st2, float* st3,
+                    float lr, float beta1, float beta2, float eps, void* stream);
+
+/* Dense-side FM gradients: dwd[j] = sum_b g[b]*dense[b][j], dbias = sum_b g[b]
+ * (fixed-order sums).  out = dwd[n_dense] followed by dbias. */
+int mi_fm_bwd_dense(const float* g, const float* dense, int n_dense, int64_t B, float* out,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355REC_H */

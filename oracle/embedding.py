@@ -1,0 +1,138 @@
+"""Numpy restatement of bag pooling and of the sort-by-row sparse backward
+(TEST INFRASTRUCTURE ONLY).
+
+Bag pooling is the gather identity of the reference's first layers:
+``n_hot(x) @ W == sum_j W[x_j]`` (r_model.py:68-80 feeding :53-54) and a
+negative id contributes nothing (r_model.py:82-96).  The sparse backward has
+no reference counterpart (TensorFlow forms the dense ``X^T dY``,
+model_trainer.py:157-158); its oracle here is numpy's stable argsort /
+unique, which the device artefacts must match bit for bit, and
+``dense_grad`` must equal ``X^T dY`` computed from materialised one-hots.
+"""
+import numpy as np
+
+
+def bag_slices(indices, offsets, bag_len, n_bags):
+    flat = np.asarray(indices).reshape(-1)
+    for i in range(n_bags):
+        if offsets is not None:
+            yield i, flat[int(offsets[i]):int(offsets[i + 1])]
+        else:
+            yield i, flat[i * bag_len:(i + 1) * bag_len]
+
+
+def embag_fwd(weights, table_offsets, T, indices, offsets=None, bag_len=None, mode='sum', bias=None,
+              dtype=np.float64):
+    """out[b, t*dim:(t+1)*dim] = pool over valid ids of bag b*T+t; sequential summation."""
+    weights = np.asarray(weights)
+    dim = weights.shape[1]
+    flat = np.asarray(indices).reshape(-1)
+    if offsets is None:
+        if bag_len is None:
+            bag_len = np.asarray(indices).shape[-1] if np.asarray(indices).ndim > 1 else 1
+        n_bags = flat.size // max(bag_len, 1)
+    else:
+        n_bags = len(offsets) - 1
+    out = np.zeros((n_bags // T, T * dim), dtype=dtype)
+    for i, ids in bag_slices(indices, offsets, bag_len, n_bags):
+        t = i % T
+        base = int(table_offsets[t])
+        rows = int(table_offsets[t + 1]) - base
+        acc = np.zeros(dim, dtype=dtype)
+        cnt = 0
+        for v in ids:
+            v = int(v)
+            if 0 <= v < rows:
+                acc += weights[base + v].astype(dtype)
+                cnt += 1
+        if mode == 'mean' and cnt > 1:
+            acc /= cnt
+        if bias is not None:
+            acc += np.asarray(bias, dtype=dtype)[t * dim:(t + 1) * dim]
+        out[i // T, t * dim:(t + 1) * dim] = acc
+    return out
+
+
+def entry_keys(table_offsets, T, indices, offsets=None, bag_len=None):
+    """Global row of every entry (sentinel = total_rows for padding / invalid), entry->bag map."""
+    flat = np.asarray(indices).reshape(-1).astype(np.int64)
+    n = flat.size
+    if offsets is None:
+        if bag_len is None:
+            bag_len = np.asarray(indices).shape[-1] if np.asarray(indices).ndim > 1 else 1
+        bag = np.arange(n) // max(bag_len, 1)
+    else:
+        offsets = np.asarray(offsets)
+        bag = np.searchsorted(offsets, np.arange(n), side='right') - 1
+    t = bag % T
+    toffs = np.asarray(table_offsets, dtype=np.int64)
+    rows = toffs[t + 1] - toffs[t]
+    total = int(toffs[-1])
+    valid = (flat >= 0) & (flat < rows)
+    keys = np.where(valid, toffs[t] + flat, total)
+    return keys, bag, total
+
+
+def prepare(table_offsets, T, indices, offsets=None, bag_len=None):
+    """(sorted_rows, perm, unique_rows, seg_offsets) restricted to valid entries."""
+    keys, bag, total = entry_keys(table_offsets, T, indices, offsets, bag_len)
+    perm = np.argsort(keys, kind='stable')
+    sorted_rows = keys[perm]
+    n_valid = int((sorted_rows != total).sum())
+    sorted_rows, perm = sorted_rows[:n_valid], perm[:n_valid]
+    unique_rows, first = np.unique(sorted_rows, return_index=True)
+    seg_offsets = np.concatenate([first, [n_valid]]).astype(np.int32)
+    return sorted_rows, perm.astype(np.int32), unique_rows, seg_offsets
+
+
+def row_grads(table_offsets, T, indices, grad_out, dim, offsets=None, bag_len=None, mode='sum',
+              dtype=np.float64):
+    """dict row -> summed gradient (sequential in sorted order)."""
+    keys, bag, total = entry_keys(table_offsets, T, indices, offsets, bag_len)
+    grad_out = np.asarray(grad_out, dtype=dtype)
+    counts = np.bincount(bag[keys != total], minlength=bag.max() + 1 if bag.size else 0)
+    out = {}
+    order = np.argsort(keys, kind='stable')
+    for p in order:
+        k = int(keys[p])
+        if k == total:
+            break
+        b, t = int(bag[p]) // T, int(bag[p]) % T
+        g = grad_out[b, t * dim:(t + 1) * dim]
+        if mode == 'mean' and counts[bag[p]] > 1:
+            g = g / counts[bag[p]]
+        out[k] = out.get(k, np.zeros(dim, dtype=dtype)) + g
+    return out
+
+
+def dense_grad(total_rows, dim, grads, dtype=np.float64):
+    dW = np.zeros((total_rows, dim), dtype=dtype)
+    for r, g in grads.items():
+        dW[r] = g
+    return dW
+
+
+def apply_sgd(w, grads, lr):
+    for r, g in grads.items():
+        w[r] -= lr * g
+
+
+def apply_adagrad_rowwise(w, state, grads, lr, eps):
+    for r, g in grads.items():
+        state[r] += np.mean(g * g)
+        w[r] -= lr * g / (np.sqrt(state[r]) + eps)
+
+
+def adam_lr_t(lr, beta1, beta2, t):
+    return lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+
+
+def apply_adam_tf(w, m, v, grads, lr_t, beta1, beta2, eps, dense=False):
+    """TensorFlow-form Adam; ``dense`` also decays/moves rows absent from ``grads``."""
+    rows = range(w.shape[0]) if dense else grads.keys()
+    zero = np.zeros(w.shape[1:], dtype=w.dtype)
+    for r in rows:
+        g = grads.get(r, zero)
+        m[r] = beta1 * m[r] + (1 - beta1) * g
+        v[r] = beta2 * v[r] + (1 - beta2) * g * g
+        w[r] -= lr_t * m[r] / (np.sqrt(v[r]) + eps)

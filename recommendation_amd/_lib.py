@@ -1,0 +1,97 @@
+"""ctypes binding of libmi355rec.so (the C ABI declared in include/mi355rec.h).
+
+There is no CPU fallback: if the shared library is missing the import of any
+op raises, so a GPU run can never silently pass on something else.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmi355rec.so')
+
+MI_CHECK_RANGE, MI_CHECK_INCREASING, MI_CHECK_NONNEG = 1, 2, 4
+MI_IDERR_RANGE, MI_IDERR_ORDER, MI_IDERR_INTERNAL = 1, 2, 4
+MI_POOL_SUM, MI_POOL_MEAN = 0, 1
+MI_DT_F32, MI_DT_BF16 = 0, 1
+MI_OPT_SGD, MI_OPT_ADAGRAD_ROWWISE, MI_OPT_ADAM_TF = 0, 1, 2
+
+
+class MiError(RuntimeError):
+    """A C-ABI call returned a negative MI_ERR_* code."""
+
+
+class BwdPlan(Structure):
+    """struct mi_bwd_plan"""
+    _fields_ = [
+        ('sorted_rows', c_void_p), ('perm', c_void_p), ('unique_rows', c_void_p),
+        ('seg_offsets', c_void_p), ('counts', c_void_p),
+        ('n_entries', c_int64), ('n_bags', c_int64), ('offsets', c_void_p),
+        ('bag_len', c_int), ('T', c_int), ('pool_mode', c_int), ('long_list', c_void_p),
+        ('indices', c_void_p), ('idx_bits', c_int), ('table_offsets', c_void_p),
+    ]
+
+
+P = c_void_p
+_SIGNATURES = {
+    'mi_version': (c_char_p, []),
+    'mi_last_error': (c_char_p, []),
+    'mi_embag_fwd': (c_int, [P, P, c_int, c_int, P, c_int, P, c_int, c_int64, c_int, c_int, P, P, c_int,
+                             c_int64, P, P]),
+    'mi_onehot_dense': (c_int, [P, c_int, c_int, c_int64, c_int, c_int, P, P, P]),
+    'mi_validate_ids': (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P, P]),
+    'mi_embag_bwd_workspace_bytes': (c_size_t, [c_int64]),
+    'mi_embag_bwd_prepare': (c_int, [P, c_int, c_int64, P, c_int, P, c_int, c_int64, c_int64, P, P, P, P, P,
+                                     P, c_size_t, P]),
+    'mi_sort_pairs_u32': (c_int, [P, P, c_int64, c_int, P, c_size_t, P]),
+    'mi_embag_bwd_dense_grad': (c_int, [POINTER(BwdPlan), P, c_int64, c_int, c_int64, P, P]),
+    'mi_embag_bwd_apply_sgd': (c_int, [POINTER(BwdPlan), P, c_int64, c_int, P, c_float, P]),
+    'mi_embag_bwd_apply_adagrad_rowwise': (c_int, [POINTER(BwdPlan), P, c_int64, c_int, P, P, c_float, c_float, P]),
+    'mi_embag_bwd_apply_adam_tf': (c_int, [POINTER(BwdPlan), P, c_int64, c_int, P, P, P, c_float, c_float,
+                                           c_float, c_float, P]),
+    'mi_embag_bwd_apply_adam_dense_tf': (c_int, [POINTER(BwdPlan), P, c_int64, c_int, c_int64, P, P, P, c_float,
+                                                 c_float, c_float, c_float, P]),
+    'mi_linear_fwd': (c_int, [P, c_int64, P, P, P, c_int64, c_int64, c_int, c_int, P]),
+    'mi_linear_bwd_workspace_bytes': (c_size_t, [c_int64, c_int, c_int]),
+    'mi_linear_bwd': (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int64, c_int, c_int, P, c_size_t, P]),
+    'mi_softmax_heads': (c_int, [P, c_int64, c_int64, c_int, c_int, P, P, c_float, P, P, P, P, P, P, P]),
+    'mi_hit_rows': (c_int, [P, P, c_int64, c_int, P, P]),
+    'mi_colsum': (c_int, [P, c_int64, c_int64, c_int, P, P]),
+    'mi_reduce_sum': (c_int, [P, c_int64, c_float, P, P]),
+    'mi_adam_tf_dense': (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P]),
+    'mi_fm_fwd': (c_int, [P, P, P, c_int, c_int, P, c_int, c_int64, P, c_int, P, P, P, c_float, P, P, P, P, P, P]),
+    'mi_fm_bwd_apply': (c_int, [POINTER(BwdPlan), P, P, c_int, P, P, c_int, P, P, P, P, c_float, c_float, c_float,
+                                c_float, P]),
+    'mi_fm_bwd_dense': (c_int, [P, P, c_int, c_int64, P, P]),
+}
+
+EXPORTS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise with a build hint when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MiError(
+            "%s not found: build it with `make -C %s` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the HIP path." % (LIB_PATH, os.path.join(_HERE, 'csrc')))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header and library out of step
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise MiError on a negative code."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise MiError("%s failed (%d): %s" % (name, rc, lib.mi_last_error().decode()))
+    return rc

@@ -1,0 +1,299 @@
+// Embedding gather + sum/mean pooling, dense one-hot materialisation, id validation.
+//
+// The reference turns categorical ids into dense one-hot / n-hot matrices
+// (recommendation/code/r_model.py:60-96) and multiplies them into the first
+// tf.layers.dense kernel of each tower (r_model.py:53-54).  one_hot(x) @ W == W[x] and
+// n_hot(x) @ W == sum_j W[x_j], so the same numbers come from a row gather with sum
+// pooling; that is what embag_fwd_kernel does, for all tables of a model in one launch.
+//
+// Thread mapping: a bag (one sample's ids for one table) is served by dim/VEC adjacent
+// lanes, each owning VEC consecutive columns of the pooled row; no cross-lane reduction
+// is needed and the pooled output of a block is one contiguous, fully coalesced store.
+// Row reads are 16 B per lane (VEC = 4), i.e. a 64 B row is one 4-lane segment.
+#include "common.h"
+
+namespace {
+
+template <int VEC>
+struct Acc {
+  float v[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ void ld_row(const float* p, Acc<VEC>& a);
+template <>
+__device__ __forceinline__ void ld_row<4>(const float* p, Acc<4>& a) {
+  const float4 q = *reinterpret_cast<const float4*>(p);
+  a.v[0] = q.x; a.v[1] = q.y; a.v[2] = q.z; a.v[3] = q.w;
+}
+template <>
+__device__ __forceinline__ void ld_row<1>(const float* p, Acc<1>& a) {
+  a.v[0] = *p;
+}
+
+template <int VEC, bool BF16>
+__device__ __forceinline__ void st_out(void* out, int64_t off, const Acc<VEC>& a) {
+  if constexpr (BF16) {
+    unsigned short* o = reinterpret_cast<unsigned short*>(out) + off;
+    if constexpr (VEC == 4) {
+      ushort4 q;
+      q.x = mi_f2bf(a.v[0]); q.y = mi_f2bf(a.v[1]); q.z = mi_f2bf(a.v[2]); q.w = mi_f2bf(a.v[3]);
+      *reinterpret_cast<ushort4*>(o) = q;
+    } else {
+      o[0] = mi_f2bf(a.v[0]);
+    }
+  } else {
+    float* o = reinterpret_cast<float*>(out) + off;
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(o) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    } else {
+      o[0] = a.v[0];
+    }
+  }
+}
+
+constexpr int EMBAG_BLOCK = 256;
+constexpr int UNROLL = 4;
+
+template <typename IDX, int VEC, bool BF16>
+__global__ __launch_bounds__(EMBAG_BLOCK) void embag_fwd_kernel(
+    const float* __restrict__ weights, const int64_t* __restrict__ toffs, int T, int dim, int lanes,
+    int bags_per_block, const void* __restrict__ indices, const int64_t* __restrict__ offsets,
+    int bag_len, int n_bags, int pool_mode, int flags, const float* __restrict__ bias,
+    void* __restrict__ out, int64_t out_ld, int32_t* __restrict__ err) {
+  const int sub = threadIdx.x / lanes;
+  const int c = threadIdx.x - sub * lanes;
+  if (sub >= bags_per_block) return;
+  const int bag = blockIdx.x * bags_per_block + sub;
+  if (bag >= n_bags) return;
+  const int b = bag / T;
+  const int t = bag - b * T;
+  const int64_t base = toffs[t];
+  const int64_t rows = toffs[t + 1] - base;
+  int64_t beg, end;
+  if (offsets) {
+    beg = offsets[bag];
+    end = offsets[bag + 1];
+  } else {
+    beg = (int64_t) bag * bag_len;
+    end = beg + bag_len;
+  }
+  Acc<VEC> acc;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc.v[k] = 0.f;
+  int count = 0;
+  int bad = 0;
+  int64_t prev = -1;
+  const float* wcol = weights + (int64_t) c * VEC;
+  for (int64_t j0 = beg; j0 < end; j0 += UNROLL) {
+    int64_t id[UNROLL];
+    bool ok[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t j = j0 + u;
+      id[u] = (j < end) ? mi_ld_id<IDX>(indices, j) : (int64_t) -1;
+      const bool present = (j < end);
+      if (present) {
+        if (id[u] < 0) {
+          if (flags & MI_CHECK_NONNEG) bad |= MI_IDERR_RANGE;
+        } else {
+          if (id[u] >= rows && (flags & MI_CHECK_RANGE)) bad |= MI_IDERR_RANGE;
+          if (flags & MI_CHECK_INCREASING) {
+            if (id[u] <= prev) bad |= MI_IDERR_ORDER;
+            prev = id[u];
+          }
+        }
+      }
+      ok[u] = present && id[u] >= 0 && id[u] < rows;  // an id outside the table is never dereferenced
+    }
+    Acc<VEC> r[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t row = ok[u] ? (base + id[u]) : base;
+      if (ok[u]) {
+        ld_row<VEC>(wcol + row * dim, r[u]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) r[u].v[k] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc.v[k] += r[u].v[k];
+      count += ok[u] ? 1 : 0;
+    }
+  }
+  if (pool_mode == MI_POOL_MEAN && count > 1) {
+    const float inv = 1.0f / (float) count;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc.v[k] *= inv;
+  }
+  if (bias) {
+    Acc<VEC> bv;
+    ld_row<VEC>(bias + (int64_t) t * dim + (int64_t) c * VEC, bv);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc.v[k] += bv.v[k];
+  }
+  st_out<VEC, BF16>(out, (int64_t) b * out_ld + (int64_t) t * dim + (int64_t) c * VEC, acc);
+  if (bad && c == 0 && err) atomicOr(err, bad);
+}
+
+template <typename IDX>
+__global__ __launch_bounds__(256) void onehot_dense_kernel(const void* __restrict__ indices, int bag_len,
+                                                          int n_bags, int size, int flags,
+                                                          float* __restrict__ out,
+                                                          int32_t* __restrict__ err) {
+  // one thread per (bag, column); the ids of a bag are few, so each thread scans them.
+  const int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t) n_bags * size;
+  if (g >= total) return;
+  const int bag = (int) (g / size);
+  const int col = (int) (g - (int64_t) bag * size);
+  float v = 0.f;
+  int bad = 0;
+  int64_t prev = -1;
+  for (int j = 0; j < bag_len; ++j) {
+    const int64_t id = mi_ld_id<IDX>(indices, (int64_t) bag * bag_len + j);
+    if (id < 0) {
+      if (flags & MI_CHECK_NONNEG) bad |= MI_IDERR_RANGE;
+      continue;
+    }
+    if (id >= size && (flags & MI_CHECK_RANGE)) bad |= MI_IDERR_RANGE;
+    if (flags & MI_CHECK_INCREASING) {
+      if (id <= prev) bad |= MI_IDERR_ORDER;
+      prev = id;
+    }
+    if (id == col) v = 1.0f;
+  }
+  out[g] = v;
+  if (bad && col == 0 && err) atomicOr(err, bad);
+}
+
+template <typename IDX>
+__global__ __launch_bounds__(256) void validate_kernel(const int64_t* __restrict__ toffs, int T,
+                                                      const void* __restrict__ indices,
+                                                      const int64_t* __restrict__ offsets, int bag_len,
+                                                      int n_bags, int flags, int32_t* __restrict__ err) {
+  const int bag = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bag >= n_bags) return;
+  const int t = bag % T;
+  const int64_t rows = toffs[t + 1] - toffs[t];
+  int64_t beg, end;
+  if (offsets) {
+    beg = offsets[bag];
+    end = offsets[bag + 1];
+  } else {
+    beg = (int64_t) bag * bag_len;
+    end = beg + bag_len;
+  }
+  int bad = 0;
+  int64_t prev = -1;
+  for (int64_t j = beg; j < end; ++j) {
+    const int64_t id = mi_ld_id<IDX>(indices, j);
+    if (id < 0) {
+      if (flags & MI_CHECK_NONNEG) bad |= MI_IDERR_RANGE;
+      continue;
+    }
+    if (id >= rows && (flags & MI_CHECK_RANGE)) bad |= MI_IDERR_RANGE;
+    if (flags & MI_CHECK_INCREASING) {
+      if (id <= prev) bad |= MI_IDERR_ORDER;
+      prev = id;
+    }
+  }
+  if (bad) atomicOr(err, bad);
+}
+
+template <typename IDX>
+int launch_fwd(const float* weights, const int64_t* toffs, int T, int dim, const void* indices,
+               const int64_t* offsets, int bag_len, int n_bags, int pool_mode, int flags, const float* bias,
+               void* out, int out_dtype, int64_t out_ld, int32_t* err, hipStream_t s) {
+  const bool vec4 = (dim % 4 == 0) && (((uintptr_t) weights & 15) == 0) && (out_ld % 4 == 0) &&
+                    (((uintptr_t) bias & 15) == 0) &&
+                    (((uintptr_t) out & (out_dtype == MI_DT_BF16 ? 7 : 15)) == 0);
+  const int vec = vec4 ? 4 : 1;
+  const int lanes = dim / vec;
+  MI_REQUIRE(lanes >= 1 && lanes <= EMBAG_BLOCK, "mi_embag_fwd: dim %d needs %d lanes per bag (max %d)", dim,
+             lanes, EMBAG_BLOCK);
+  const int bpb = EMBAG_BLOCK / lanes;
+  const unsigned grid = (unsigned) mi_cdiv(n_bags, bpb);
+#define LAUNCH(V, BF)                                                                                   \
+  hipLaunchKernelGGL((embag_fwd_kernel<IDX, V, BF>), dim3(grid), dim3(EMBAG_BLOCK), 0, s, weights, toffs, T, \
+                     dim, lanes, bpb, indices, offsets, bag_len, n_bags, pool_mode, flags, bias, out, out_ld, err)
+  if (out_dtype == MI_DT_BF16) {
+    if (vec4) LAUNCH(4, true); else LAUNCH(1, true);
+  } else {
+    if (vec4) LAUNCH(4, false); else LAUNCH(1, false);
+  }
+#undef LAUNCH
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+}  // namespace
+
+extern "C" int mi_embag_fwd(const float* weights, const int64_t* table_offsets, int T, int dim,
+                            const void* indices, int idx_bits, const int64_t* offsets, int bag_len,
+                            int64_t n_bags, int pool_mode, int check_flags, const float* bias, void* out,
+                            int out_dtype, int64_t out_ld, int32_t* err, void* stream) {
+  if (n_bags == 0) return MI_OK;  // empty batch: nothing to read or write
+  MI_REQUIRE(weights && table_offsets && indices && out, "mi_embag_fwd: null pointer");
+  MI_REQUIRE(T >= 1 && dim >= 1, "mi_embag_fwd: T=%d dim=%d", T, dim);
+  MI_REQUIRE(idx_bits == 32 || idx_bits == 64, "mi_embag_fwd: idx_bits must be 32 or 64");
+  MI_REQUIRE(n_bags >= 0 && n_bags < (int64_t) 1 << 31, "mi_embag_fwd: n_bags out of range");
+  MI_REQUIRE(n_bags % T == 0, "mi_embag_fwd: n_bags (%lld) must be a multiple of T (%d)", (long long) n_bags, T);
+  MI_REQUIRE(offsets || bag_len >= 0, "mi_embag_fwd: bag_len < 0 without offsets");
+  MI_REQUIRE(pool_mode == MI_POOL_SUM || pool_mode == MI_POOL_MEAN, "mi_embag_fwd: bad pool_mode");
+  MI_REQUIRE(out_dtype == MI_DT_F32 || out_dtype == MI_DT_BF16, "mi_embag_fwd: bad out_dtype");
+  MI_REQUIRE(out_ld >= (int64_t) T * dim, "mi_embag_fwd: out_ld %lld < T*dim %lld", (long long) out_ld,
+             (long long) T * dim);
+  if (n_bags == 0) return MI_OK;
+  hipStream_t s = (hipStream_t) stream;
+  if (idx_bits == 32)
+    return launch_fwd<int32_t>(weights, table_offsets, T, dim, indices, offsets, bag_len, (int) n_bags,
+                               pool_mode, check_flags, bias, out, out_dtype, out_ld, err, s);
+  return launch_fwd<int64_t>(weights, table_offsets, T, dim, indices, offsets, bag_len, (int) n_bags, pool_mode,
+                             check_flags, bias, out, out_dtype, out_ld, err, s);
+}
+
+extern "C" int mi_onehot_dense(const void* indices, int idx_bits, int bag_len, int64_t n_bags, int size,
+                               int check_flags, float* out, int32_t* err, void* stream) {
+  if (n_bags == 0) return MI_OK;
+  MI_REQUIRE(indices && out, "mi_onehot_dense: null pointer");
+  MI_REQUIRE(idx_bits == 32 || idx_bits == 64, "mi_onehot_dense: idx_bits must be 32 or 64");
+  MI_REQUIRE(bag_len >= 1 && size >= 1, "mi_onehot_dense: bag_len=%d size=%d", bag_len, size);
+  MI_REQUIRE(n_bags >= 0 && n_bags < (int64_t) 1 << 31, "mi_onehot_dense: n_bags out of range");
+  if (n_bags == 0) return MI_OK;
+  const int64_t total = n_bags * size;
+  const unsigned grid = (unsigned) mi_cdiv(total, 256);
+  hipStream_t s = (hipStream_t) stream;
+  if (idx_bits == 32)
+    hipLaunchKernelGGL(onehot_dense_kernel<int32_t>, dim3(grid), dim3(256), 0, s, indices, bag_len, (int) n_bags,
+                       size, check_flags, out, err);
+  else
+    hipLaunchKernelGGL(onehot_dense_kernel<int64_t>, dim3(grid), dim3(256), 0, s, indices, bag_len, (int) n_bags,
+                       size, check_flags, out, err);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_validate_ids(const int64_t* table_offsets, int T, const void* indices, int idx_bits,
+                               const int64_t* offsets, int bag_len, int64_t n_bags, int check_flags,
+                               int32_t* err, void* stream) {
+  if (n_bags == 0) return MI_OK;
+  MI_REQUIRE(table_offsets && indices && err, "mi_validate_ids: null pointer");
+  MI_REQUIRE(T >= 1, "mi_validate_ids: T=%d", T);
+  MI_REQUIRE(idx_bits == 32 || idx_bits == 64, "mi_validate_ids: idx_bits must be 32 or 64");
+  MI_REQUIRE(n_bags >= 0 && n_bags < (int64_t) 1 << 31, "mi_validate_ids: n_bags out of range");
+  if (n_bags == 0) return MI_OK;
+  const unsigned grid = (unsigned) mi_cdiv(n_bags, 256);
+  hipStream_t s = (hipStream_t) stream;
+  if (idx_bits == 32)
+    hipLaunchKernelGGL(validate_kernel<int32_t>, dim3(grid), dim3(256), 0, s, table_offsets, T, indices, offsets,
+                       bag_len, (int) n_bags, check_flags, err);
+  else
+    hipLaunchKernelGGL(validate_kernel<int64_t>, dim3(grid), dim3(256), 0, s, table_offsets, T, indices, offsets,
+                       bag_len, (int) n_bags, check_flags, err);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}

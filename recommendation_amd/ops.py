@@ -1,0 +1,347 @@
+"""Torch-tensor wrappers over the C ABI (libmi355rec.so).
+
+PyTorch is used for device memory and streams only: every arithmetic step
+below is one call into a hand-written HIP kernel on torch's current stream.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (MI_CHECK_INCREASING, MI_CHECK_NONNEG, MI_CHECK_RANGE, MI_DT_BF16, MI_DT_F32,
+                   MI_IDERR_ORDER, MI_IDERR_RANGE, MI_OPT_ADAGRAD_ROWWISE, MI_OPT_ADAM_TF, MI_OPT_SGD,
+                   MI_POOL_MEAN, MI_POOL_SUM, BwdPlan, MiError)
+
+
+class InvalidArgumentError(ValueError):
+    """Raised where TensorFlow would raise ``tf.errors.InvalidArgumentError`` (an id out
+    of range, or the ids of an n-hot row repeated / out of order)."""
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise MiError("the HIP path needs device tensors; got a %s tensor (no CPU fallback)" % t.device)
+
+
+def _idx_bits(idx):
+    if idx.dtype == torch.int32:
+        return 32
+    if idx.dtype == torch.int64:
+        return 64
+    raise TypeError("ids must be int32 or int64, got %s" % idx.dtype)
+
+
+def new_error_word(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def check_error_word(err, what="ids"):
+    """Synchronising read of the device error word; raises like TensorFlow would."""
+    code = int(err.item())
+    if code:
+        err.zero_()
+        msgs = []
+        if code & MI_IDERR_RANGE:
+            msgs.append("index out of bounds")
+        if code & MI_IDERR_ORDER:
+            msgs.append("indices of a row are out of order or repeated")
+        if code & ~(MI_IDERR_RANGE | MI_IDERR_ORDER):
+            msgs.append("internal device error 0x%x" % code)
+        raise InvalidArgumentError("%s: %s" % (what, '; '.join(msgs)))
+
+
+def table_offsets(rows_per_table, device):
+    """int64 [T+1] global row offsets for tables stored back to back."""
+    offs = [0]
+    for r in rows_per_table:
+        offs.append(offs[-1] + int(r))
+    return torch.tensor(offs, dtype=torch.int64, device=device)
+
+
+# ----------------------------------------------------------------------------- forward
+def embag_fwd(weights, toffs, T, indices, offsets=None, bag_len=None, pool_mode=MI_POOL_SUM, check_flags=0,
+              bias=None, err=None, out=None, out_dtype=torch.float32, out_ld=None, n_bags=None):
+    """Pooled embedding rows for all bags of all T tables (one launch)."""
+    _need_cuda(weights, toffs, indices, offsets, bias, err, out)
+    dim = weights.shape[1]
+    if offsets is None:
+        if bag_len is None:
+            bag_len = indices.shape[-1] if indices.dim() > 1 else 1
+        if n_bags is None:
+            n_bags = indices.numel() // max(bag_len, 1)
+    else:
+        n_bags = offsets.numel() - 1
+        bag_len = 0
+    B = n_bags // T
+    if out_ld is None:
+        out_ld = T * dim
+    if out is None:
+        out = torch.empty((B, out_ld), dtype=out_dtype, device=weights.device)
+    dt = MI_DT_BF16 if out.dtype == torch.bfloat16 else MI_DT_F32
+    indices = indices.contiguous()
+    _lib.call('mi_embag_fwd', _p(weights), _p(toffs), T, dim, _p(indices), _idx_bits(indices), _p(offsets),
+              bag_len, n_bags, pool_mode, check_flags, _p(bias), _p(out), dt, out_ld, _p(err), _stream())
+    return out
+
+
+def onehot_dense(indices, size, check_flags=0, err=None):
+    _need_cuda(indices, err)
+    idx = indices.contiguous()
+    if idx.dim() == 1:
+        idx = idx.view(-1, 1)
+    n_bags, bag_len = idx.shape
+    out = torch.empty((n_bags, size), dtype=torch.float32, device=idx.device)
+    _lib.call('mi_onehot_dense', _p(idx), _idx_bits(idx), bag_len, n_bags, size, check_flags, _p(out), _p(err),
+              _stream())
+    return out
+
+
+def validate_ids(toffs, T, indices, check_flags, err, offsets=None, bag_len=None):
+    _need_cuda(toffs, indices, err, offsets)
+    idx = indices.contiguous()
+    if offsets is None:
+        if bag_len is None:
+            bag_len = idx.shape[-1] if idx.dim() > 1 else 1
+        n_bags = idx.numel() // max(bag_len, 1)
+    else:
+        n_bags, bag_len = offsets.numel() - 1, 0
+    _lib.call('mi_validate_ids', _p(toffs), T, _p(idx), _idx_bits(idx), _p(offsets), bag_len, n_bags, check_flags,
+              _p(err), _stream())
+
+
+# ----------------------------------------------------------------------------- sparse backward
+class SortedPlan(object):
+    """Device artefacts of ``mi_embag_bwd_prepare`` plus the struct the apply calls take."""
+
+    def __init__(self, toffs, T, total_rows, indices, offsets=None, bag_len=None, pool_mode=MI_POOL_SUM,
+                 workspace=None):
+        _need_cuda(toffs, indices, offsets)
+        dev = indices.device
+        self.indices = indices.contiguous()
+        self.offsets = offsets
+        self.toffs = toffs
+        self.T = T
+        self.total_rows = int(total_rows)
+        n = self.indices.numel()
+        if offsets is None:
+            if bag_len is None:
+                bag_len = self.indices.shape[-1] if self.indices.dim() > 1 else 1
+            n_bags = n // max(bag_len, 1)
+        else:
+            n_bags, bag_len = offsets.numel() - 1, 0
+        self.n_entries, self.n_bags, self.bag_len = n, n_bags, bag_len
+        self.sorted_rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)  # uint32 bit patterns
+        self.perm = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        self.unique_rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        self.seg_offsets = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        self.counts = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.long_list = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        ws_bytes = _lib.load().mi_embag_bwd_workspace_bytes(n)
+        if workspace is None or workspace.numel() < ws_bytes:
+            workspace = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        self.workspace = workspace
+        self.pool_mode = pool_mode
+        self._bind()
+        self.prepare()
+
+    def prepare(self, indices=None):
+        """(Re)run the sort. ``indices`` must have the shape/dtype this plan was built for;
+        no device memory is allocated, so the call can sit inside a captured graph."""
+        if indices is not None:
+            indices = indices.contiguous()
+            if indices.numel() != self.n_entries or indices.dtype != self.indices.dtype:
+                raise MiError("SortedPlan.prepare: indices shape/dtype differ from the plan's")
+            self.indices = indices
+            self._bind()
+        _lib.call('mi_embag_bwd_prepare', _p(self.toffs), self.T, self.total_rows, _p(self.indices),
+                  _idx_bits(self.indices), _p(self.offsets), self.bag_len, self.n_bags, self.n_entries,
+                  _p(self.sorted_rows), _p(self.perm), _p(self.unique_rows), _p(self.seg_offsets), _p(self.counts),
+                  _p(self.workspace), self.workspace.numel(), _stream())
+        return self
+
+    def _bind(self):
+        n, n_bags, bag_len, T, offsets, toffs = (self.n_entries, self.n_bags, self.bag_len, self.T, self.offsets,
+                                                 self.toffs)
+        pool_mode = self.pool_mode
+        self.c = BwdPlan(
+            sorted_rows=self.sorted_rows.data_ptr(), perm=self.perm.data_ptr(),
+            unique_rows=self.unique_rows.data_ptr(), seg_offsets=self.seg_offsets.data_ptr(),
+            counts=self.counts.data_ptr(), n_entries=n, n_bags=n_bags,
+            offsets=offsets.data_ptr() if offsets is not None else None, bag_len=bag_len, T=T,
+            pool_mode=pool_mode, long_list=self.long_list.data_ptr(), indices=self.indices.data_ptr(),
+            idx_bits=_idx_bits(self.indices), table_offsets=toffs.data_ptr())
+
+    def ref(self):
+        return ctypes.byref(self.c)
+
+    def host(self):
+        """(sorted_rows, perm, unique_rows, seg_offsets) trimmed to their valid lengths, on the host."""
+        n_unique, n_valid = (int(v) for v in self.counts.tolist())
+        u32 = lambda t, k: (t[:k].cpu().numpy().astype('int64') & 0xFFFFFFFF)
+        return (u32(self.sorted_rows, n_valid), self.perm[:n_valid].cpu().numpy(), u32(self.unique_rows, n_unique),
+                self.seg_offsets[:n_unique + 1].cpu().numpy())
+
+
+def sort_pairs_u32(keys, vals, key_bits=32):
+    """In-place stable radix sort of int32-typed tensors holding uint32 bit patterns."""
+    _need_cuda(keys, vals)
+    n = keys.numel()
+    ws_bytes = _lib.load().mi_embag_bwd_workspace_bytes(n)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=keys.device)
+    _lib.call('mi_sort_pairs_u32', _p(keys), _p(vals), n, key_bits, _p(ws), ws.numel(), _stream())
+    return keys, vals
+
+
+def bwd_dense_grad(plan, grad_out, dim, total_rows, grad_ld=None):
+    grad_out = grad_out.contiguous()
+    dW = torch.empty((total_rows, dim), dtype=torch.float32, device=grad_out.device)
+    _lib.call('mi_embag_bwd_dense_grad', plan.ref(), _p(grad_out), grad_ld or grad_out.shape[-1], dim, total_rows,
+              _p(dW), _stream())
+    return dW
+
+
+def bwd_apply_sgd(plan, grad_out, weights, lr, grad_ld=None):
+    _lib.call('mi_embag_bwd_apply_sgd', plan.ref(), _p(grad_out), grad_ld or grad_out.shape[-1], weights.shape[1],
+              _p(weights), lr, _stream())
+
+
+def bwd_apply_adagrad_rowwise(plan, grad_out, weights, state, lr, eps, grad_ld=None):
+    _lib.call('mi_embag_bwd_apply_adagrad_rowwise', plan.ref(), _p(grad_out), grad_ld or grad_out.shape[-1],
+              weights.shape[1], _p(weights), _p(state), lr, eps, _stream())
+
+
+def bwd_apply_adam_tf(plan, grad_out, weights, m, v, lr_t, beta1, beta2, eps, grad_ld=None):
+    _lib.call('mi_embag_bwd_apply_adam_tf', plan.ref(), _p(grad_out), grad_ld or grad_out.shape[-1],
+              weights.shape[1], _p(weights), _p(m), _p(v), lr_t, beta1, beta2, eps, _stream())
+
+
+def bwd_apply_adam_dense_tf(plan, grad_out, weights, m, v, lr_t, beta1, beta2, eps, grad_ld=None):
+    _lib.call('mi_embag_bwd_apply_adam_dense_tf', plan.ref(), _p(grad_out), grad_ld or grad_out.shape[-1],
+              weights.shape[1], weights.shape[0], _p(weights), _p(m), _p(v), lr_t, beta1, beta2, eps, _stream())
+
+
+# ----------------------------------------------------------------------------- small dense pieces
+def linear_fwd(x, W, b=None, out=None):
+    _need_cuda(x, W, b, out)
+    assert x.stride(-1) == 1 and W.is_contiguous()
+    B, K = x.shape
+    N = W.shape[1]
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    _lib.call('mi_linear_fwd', _p(x), x.stride(0), _p(W), _p(b), _p(out), out.stride(0), B, K, N, _stream())
+    return out
+
+
+def linear_bwd(x, W, dy, need_dx=True):
+    _need_cuda(x, W, dy)
+    assert x.stride(-1) == 1 and dy.stride(-1) == 1 and W.is_contiguous()
+    B, K = x.shape
+    N = W.shape[1]
+    dev = x.device
+    dx = torch.empty((B, K), dtype=torch.float32, device=dev) if need_dx else None
+    dW = torch.empty((K, N), dtype=torch.float32, device=dev)
+    db = torch.empty((N,), dtype=torch.float32, device=dev)
+    ws_bytes = _lib.load().mi_linear_bwd_workspace_bytes(B, K, N)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    _lib.call('mi_linear_bwd', _p(x), x.stride(0), _p(W), _p(dy), dy.stride(0), _p(dx), K, _p(dW), _p(db), B, K, N,
+              _p(ws), ws.numel(), _stream())
+    return dx, dW, db
+
+
+def softmax_heads(logits, k=0, labels=None, label_ids=None, grad_scale=1.0, want_probs=False, want_top=False,
+                  want_loss=False, want_dlogits=False, want_hits=False):
+    _need_cuda(logits, labels, label_ids)
+    assert logits.stride(-1) == 1
+    B, N = logits.shape
+    dev = logits.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    probs = torch.empty((B, N), **f32) if want_probs else None
+    top_idx = torch.empty((B, k), dtype=torch.int32, device=dev) if want_top else None
+    top_val = torch.empty((B, k), **f32) if want_top else None
+    loss_rows = torch.empty((B,), **f32) if want_loss else None
+    dlogits = torch.empty((B, N), **f32) if want_dlogits else None
+    hit_rows = torch.empty((B,), **f32) if want_hits else None
+    if labels is not None:
+        labels = labels.contiguous()
+    _lib.call('mi_softmax_heads', _p(logits), logits.stride(0), B, N, k, _p(labels), _p(label_ids), grad_scale,
+              _p(probs), _p(top_idx), _p(top_val), _p(loss_rows), _p(dlogits), _p(hit_rows), _stream())
+    return dict(probs=probs, top_idx=top_idx, top_val=top_val, loss_rows=loss_rows, dlogits=dlogits,
+                hit_rows=hit_rows)
+
+
+def hit_rows(labels, preds):
+    _need_cuda(labels, preds)
+    labels = labels.contiguous().to(torch.int32)
+    preds = preds.contiguous().to(torch.int32)
+    B, k = preds.shape
+    out = torch.empty((B,), dtype=torch.float32, device=labels.device)
+    _lib.call('mi_hit_rows', _p(labels), _p(preds), B, k, _p(out), _stream())
+    return out
+
+
+def colsum(x):
+    _need_cuda(x)
+    assert x.stride(-1) == 1
+    B, N = x.shape
+    out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    _lib.call('mi_colsum', _p(x), x.stride(0), B, N, _p(out), _stream())
+    return out
+
+
+def reduce_sum(x, scale=1.0, out=None):
+    _need_cuda(x)
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    _lib.call('mi_reduce_sum', _p(x), x.numel(), scale, _p(out), _stream())
+    return out
+
+
+def adam_tf_dense(p, m, v, g, lr_t, beta1, beta2, eps):
+    _need_cuda(p, m, v, g)
+    assert p.is_contiguous() and m.is_contiguous() and v.is_contiguous() and g.is_contiguous()
+    _lib.call('mi_adam_tf_dense', _p(p), _p(m), _p(v), _p(g), p.numel(), lr_t, beta1, beta2, eps, _stream())
+
+
+# ----------------------------------------------------------------------------- FM
+def fm_fwd(V, w1, toffs, ids, dense=None, wd=None, bias=None, labels=None, gscale=1.0, err=None, out=None):
+    """Returns dict(logit, S, loss_rows, g). ``out`` may hold preallocated buffers of those names."""
+    _need_cuda(V, w1, toffs, ids, dense, wd, bias, labels, err)
+    B, T = ids.shape
+    dim = V.shape[1]
+    dev = V.device
+    out = out or {}
+    f32 = dict(dtype=torch.float32, device=dev)
+    logit = out.get('logit') if out.get('logit') is not None else torch.empty((B,), **f32)
+    S = out.get('S') if out.get('S') is not None else torch.empty((B, dim), **f32)
+    loss_rows = g = None
+    if labels is not None:
+        loss_rows = out.get('loss_rows') if out.get('loss_rows') is not None else torch.empty((B,), **f32)
+        g = out.get('g') if out.get('g') is not None else torch.empty((B,), **f32)
+    n_dense = dense.shape[1] if dense is not None else 0
+    _lib.call('mi_fm_fwd', _p(V), _p(w1), _p(toffs), T, dim, _p(ids), _idx_bits(ids), B, _p(dense), n_dense,
+              _p(wd), _p(bias), _p(labels), gscale, _p(logit), _p(S), _p(loss_rows), _p(g), _p(err), _stream())
+    return dict(logit=logit, S=S, loss_rows=loss_rows, g=g)
+
+
+def fm_bwd_apply(plan, g, S, V, w1, opt, state, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    st = list(state) + [None] * (4 - len(state))
+    _lib.call('mi_fm_bwd_apply', plan.ref(), _p(g), _p(S), V.shape[1], _p(V), _p(w1), opt, _p(st[0]), _p(st[1]),
+              _p(st[2]), _p(st[3]), lr, beta1, beta2, eps, _stream())
+
+
+def fm_bwd_dense(g, dense, out=None):
+    n_dense = dense.shape[1] if dense is not None else 0
+    if out is None:
+        out = torch.empty((n_dense + 1,), dtype=torch.float32, device=g.device)
+    _lib.call('mi_fm_bwd_dense', _p(g), _p(dense), n_dense, g.numel(), _p(out), _stream())
+    return out

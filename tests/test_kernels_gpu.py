@@ -1,0 +1,402 @@
+"""Parity of every HIP kernel, called through the C ABI, against the numpy oracle.
+
+Bars: bit-exact for ids, gathered rows, one-hot matrices and the sorted-run artefacts;
+<= 1e-5 relative for fp32 sums (tolerance stated in each test)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import colour_model as cm
+from oracle import embedding as oe
+from oracle import fm as ofm
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def make_tables(rng, rows_per_table, dim):
+    total = int(sum(rows_per_table))
+    w = rng.standard_normal((total, dim)).astype(np.float32)
+    toffs = np.concatenate([[0], np.cumsum(rows_per_table)]).astype(np.int64)
+    return w, toffs
+
+
+@pytest.mark.parametrize("dim", [1, 3, 4, 8, 16, 64, 128])
+@pytest.mark.parametrize("idx_dtype", [np.int32, np.int64])
+def test_embag_fwd_single_id_rows_bit_exact(dev, dim, idx_dtype):
+    """One id per bag: the pooled output IS the gathered row, so it must be bit-exact."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(1)
+    rows = [7, 1, 300, 1000, 3]
+    w, toffs = make_tables(rng, rows, dim)
+    B, T = 257, len(rows)
+    ids = np.stack([rng.integers(0, r, size=B) for r in rows], axis=1).astype(idx_dtype)
+    out = ops.embag_fwd(torch.from_numpy(w).to(dev), torch.from_numpy(toffs).to(dev), T,
+                        torch.from_numpy(ids).to(dev), bag_len=1)
+    expect = w[ids + toffs[:-1][None, :]].reshape(B, T * dim)
+    assert np.array_equal(out.cpu().numpy(), expect)
+
+
+@pytest.mark.parametrize("mode", ["sum", "mean"])
+@pytest.mark.parametrize("dim", [4, 8, 16, 5])
+def test_embag_fwd_fixed_bags_with_padding(dev, mode, dim):
+    from recommendation_amd import ops
+    rng = np.random.default_rng(2)
+    rows = [128, 20]
+    w, toffs = make_tables(rng, rows, dim)
+    B, T, L = 300, 2, 7
+    ids = np.stack([rng.integers(-1, rows[t], size=(B, L)) for t in range(T)], axis=1).astype(np.int32)  # [B,T,L]
+    bias = rng.standard_normal(T * dim).astype(np.float32)
+    out = ops.embag_fwd(torch.from_numpy(w).to(dev), torch.from_numpy(toffs).to(dev), T,
+                        torch.from_numpy(ids).to(dev), bag_len=L, bias=torch.from_numpy(bias).to(dev),
+                        pool_mode=ops.MI_POOL_MEAN if mode == "mean" else ops.MI_POOL_SUM)
+    expect = oe.embag_fwd(w, toffs, T, ids, bag_len=L, mode=mode, bias=bias)
+    assert rel_err(out.cpu().numpy(), expect) <= RTOL
+
+
+def test_embag_fwd_csr_ragged_and_empty_bags(dev):
+    from recommendation_amd import ops
+    rng = np.random.default_rng(3)
+    rows = [50, 1000, 9]
+    dim = 16
+    w, toffs = make_tables(rng, rows, dim)
+    B, T = 64, 3
+    lens = rng.integers(0, 12, size=B * T)
+    lens[::5] = 0          # empty bags
+    lens[7] = 100          # one long bag
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ids = np.concatenate([rng.integers(0, rows[i % T], size=lens[i]) for i in range(B * T)]).astype(np.int64)
+    out = ops.embag_fwd(torch.from_numpy(w).to(dev), torch.from_numpy(toffs).to(dev), T,
+                        torch.from_numpy(ids).to(dev), offsets=torch.from_numpy(offsets).to(dev))
+    expect = oe.embag_fwd(w, toffs, T, ids, offsets=offsets)
+    assert rel_err(out.cpu().numpy(), expect) <= RTOL
+    # bf16 output: one rounding of the fp32 pooled sum
+    out16 = ops.embag_fwd(torch.from_numpy(w).to(dev), torch.from_numpy(toffs).to(dev), T,
+                          torch.from_numpy(ids).to(dev), offsets=torch.from_numpy(offsets).to(dev),
+                          out_dtype=torch.bfloat16)
+    assert torch.equal(out16, out.to(torch.bfloat16))
+
+
+def test_empty_batch_is_a_no_op(dev):
+    from recommendation_amd import ops
+    w = torch.zeros((4, 8), device=dev)
+    toffs = ops.table_offsets([4], dev)
+    out = ops.embag_fwd(w, toffs, 1, torch.zeros((0, 1), dtype=torch.int32, device=dev), bag_len=1)
+    assert out.shape == (0, 8)
+
+
+def test_validation_reports_and_never_dereferences_bad_ids(dev):
+    from recommendation_amd import ops
+    w = torch.ones((10, 4), device=dev)
+    toffs = ops.table_offsets([10], dev)
+    err = ops.new_error_word(dev)
+    ids = torch.tensor([[3], [10], [2 ** 31 - 1], [-5]], dtype=torch.int32, device=dev)
+    out = ops.embag_fwd(w, toffs, 1, ids, bag_len=1, check_flags=ops.MI_CHECK_RANGE, err=err)
+    assert out.cpu().numpy().tolist() == [[1.0] * 4, [0.0] * 4, [0.0] * 4, [0.0] * 4]
+    with pytest.raises(ops.InvalidArgumentError):
+        ops.check_error_word(err)
+    # negative id is padding unless NONNEG is asked for
+    ops.validate_ids(toffs, 1, torch.tensor([[-1]], dtype=torch.int32, device=dev), ops.MI_CHECK_RANGE, err)
+    ops.check_error_word(err)
+    ops.validate_ids(toffs, 1, torch.tensor([[-1]], dtype=torch.int32, device=dev),
+                     ops.MI_CHECK_RANGE | ops.MI_CHECK_NONNEG, err)
+    with pytest.raises(ops.InvalidArgumentError):
+        ops.check_error_word(err)
+    # strictly increasing rows (tf.sparse_to_dense validate_indices): repeat and disorder both fail
+    for bad in ([[1, 1, 2]], [[2, 0, 5]]):
+        ops.validate_ids(toffs, 1, torch.tensor(bad, dtype=torch.int32, device=dev),
+                         ops.MI_CHECK_RANGE | ops.MI_CHECK_INCREASING, err)
+        with pytest.raises(ops.InvalidArgumentError):
+            ops.check_error_word(err)
+    ops.validate_ids(toffs, 1, torch.tensor([[0, 2, 5]], dtype=torch.int32, device=dev),
+                     ops.MI_CHECK_RANGE | ops.MI_CHECK_INCREASING, err)
+    ops.check_error_word(err)
+
+
+def test_onehot_dense_matches_reference_encoders_bit_exact(dev):
+    from recommendation_amd import ops
+    batch = cm.synthetic_batch(300)
+    u = ops.onehot_dense(torch.from_numpy(batch['user']).to(dev), 100)
+    assert np.array_equal(u.cpu().numpy(), cm.input_to_one_hot(batch['user'], 100))
+    r = ops.onehot_dense(torch.from_numpy(batch['recommend_colours_1']).to(dev), 128)
+    assert np.array_equal(r.cpu().numpy(), cm.input_to_n_hot(batch['recommend_colours_1'], 128, 6))
+    c = ops.onehot_dense(torch.from_numpy(batch['click_colour_1']).to(dev), 128)
+    assert np.array_equal(c.cpu().numpy(), cm.input_to_one_hot_plus(batch['click_colour_1'], 128))
+
+
+@pytest.mark.parametrize("n,bits", [(1, 32), (2, 32), (63, 8), (2048, 32), (2049, 16), (100000, 32), (300007, 26)])
+def test_radix_sort_is_stable_and_exact(dev, n, bits):
+    from recommendation_amd import ops
+    rng = np.random.default_rng(n)
+    hi = (1 << bits) - 1
+    keys = rng.integers(0, min(hi, 5000) + 1, size=n, dtype=np.uint64).astype(np.uint32)  # many duplicates
+    if n > 10:
+        keys[rng.integers(0, n, size=n // 3)] = rng.integers(0, hi + 1, size=n // 3, dtype=np.uint64).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    k = torch.from_numpy(keys.view(np.int32).copy()).to(dev)
+    v = torch.from_numpy(vals.view(np.int32).copy()).to(dev)
+    ops.sort_pairs_u32(k, v, bits)
+    order = np.argsort(keys, kind='stable')
+    assert np.array_equal(k.cpu().numpy().view(np.uint32), keys[order])
+    assert np.array_equal(v.cpu().numpy().view(np.uint32), vals[order])
+
+
+@pytest.mark.parametrize("layout", ["fixed1", "fixed7", "csr"])
+def test_bwd_prepare_artefacts_bit_exact(dev, layout):
+    from recommendation_amd import ops
+    rng = np.random.default_rng(5)
+    rows = [3, 1000, 50, 100000]
+    T = len(rows)
+    toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    B = 1000
+    offsets = None
+    if layout == "fixed1":
+        ids = np.stack([rng.integers(0, r, size=B) for r in rows], axis=1).astype(np.int64)
+        L = 1
+    elif layout == "fixed7":
+        L = 7
+        ids = np.stack([rng.integers(-1, r, size=(B, L)) for r in rows], axis=1).astype(np.int32)
+        ids[3, 1, 2] = 5000  # out of range: excluded like padding
+    else:
+        L = None
+        lens = rng.integers(0, 9, size=B * T)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        ids = np.concatenate([rng.integers(0, rows[i % T], size=lens[i]) for i in range(B * T)]).astype(np.int32)
+    plan = ops.SortedPlan(torch.from_numpy(toffs).to(dev), T, int(toffs[-1]), torch.from_numpy(ids).to(dev),
+                          offsets=None if offsets is None else torch.from_numpy(offsets).to(dev), bag_len=L)
+    got = plan.host()
+    want = oe.prepare(toffs, T, ids, offsets=offsets, bag_len=L)
+    for g, w, name in zip(got, want, ("sorted_rows", "perm", "unique_rows", "seg_offsets")):
+        assert np.array_equal(g, w), name
+
+
+def _bag_problem(rng, dim, mode):
+    rows = [3, 128, 5000]
+    T, B, L = 3, 700, 5
+    w, toffs = make_tables(rng, rows, dim)
+    ids = np.stack([rng.integers(-1, r, size=(B, L)) for r in rows], axis=1).astype(np.int32)
+    grad = rng.standard_normal((B, T * dim)).astype(np.float32)
+    return rows, T, B, L, w, toffs, ids, grad
+
+
+@pytest.mark.parametrize("mode", ["sum", "mean"])
+@pytest.mark.parametrize("dim", [4, 16, 6])
+def test_dense_grad_equals_onehot_transpose_times_dy(dev, mode, dim):
+    """dW must equal X^T dY with X the materialised n-hot matrix (TensorFlow's MatMul gradient)."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(6)
+    rows, T, B, L, w, toffs, ids, grad = _bag_problem(rng, dim, mode)
+    pm = ops.MI_POOL_MEAN if mode == "mean" else ops.MI_POOL_SUM
+    plan = ops.SortedPlan(torch.from_numpy(toffs).to(dev), T, int(toffs[-1]), torch.from_numpy(ids).to(dev),
+                          bag_len=L, pool_mode=pm)
+    dW = ops.bwd_dense_grad(plan, torch.from_numpy(grad).to(dev), dim, int(toffs[-1]))
+    expect = np.zeros((int(toffs[-1]), dim))
+    for t in range(T):
+        X = np.zeros((B, rows[t]))
+        for b in range(B):
+            for v in ids[b, t]:
+                if v >= 0:
+                    X[b, v] += 1.0      # duplicates inside a bag count twice (bag semantics)
+        if mode == "mean":
+            X /= np.maximum(X.sum(axis=1, keepdims=True), 1.0)
+        expect[toffs[t]:toffs[t + 1]] = X.T @ grad[:, t * dim:(t + 1) * dim].astype(np.float64)
+    assert rel_err(dW.cpu().numpy(), expect) <= RTOL
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad_rowwise", "adam_tf", "adam_dense_tf"])
+def test_fused_sparse_updates(dev, opt):
+    """The fused kernels = (run sums) + (optimizer formula).  The run sums are held to 1e-5
+    against the oracle by the dense-gradient test above; here the oracle's optimizer formulas
+    are fed the device's own run sums (same kernel template, same fixed order, so bitwise the
+    sums the fused kernel forms) and every updated buffer must agree to 1e-6: Adam divides by
+    sqrt(v)+eps and v is quadratic in the sum, so comparing through an independently rounded
+    fp64 sum would test fp32 conditioning, not the kernel."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(7)
+    dim = 16
+    rows, T, B, L, w, toffs, ids, grad = _bag_problem(rng, dim, "sum")
+    ids[:, 0, :] = rng.integers(0, 3, size=(B, L))   # table of 3 rows: runs of ~1100 entries (long path)
+    total = int(toffs[-1])
+    plan = ops.SortedPlan(torch.from_numpy(toffs).to(dev), T, total, torch.from_numpy(ids).to(dev), bag_len=L)
+    g = torch.from_numpy(grad).to(dev)
+    wd = torch.from_numpy(w.copy()).to(dev)
+    dW = ops.bwd_dense_grad(plan, g, dim, total).cpu().numpy().astype(np.float64)
+    touched = np.unique(oe.prepare(toffs, T, ids, bag_len=L)[2])
+    grads = {int(r): dW[int(r)] for r in touched}
+    want = oe.row_grads(toffs, T, ids, grad, dim, bag_len=L)
+    assert sorted(want) == sorted(grads)
+    wr = w.astype(np.float64)
+    lr, b1, b2, eps = 0.05, 0.9, 0.999, 1e-8
+    TOL = 1e-6
+    if opt == "sgd":
+        ops.bwd_apply_sgd(plan, g, wd, lr)
+        oe.apply_sgd(wr, grads, lr)
+    elif opt == "adagrad_rowwise":
+        st = rng.random(total).astype(np.float32)
+        std = torch.from_numpy(st.copy()).to(dev)
+        ops.bwd_apply_adagrad_rowwise(plan, g, wd, std, lr, eps)
+        sr = st.astype(np.float64)
+        oe.apply_adagrad_rowwise(wr, sr, grads, lr, eps)
+        assert rel_err(std.cpu().numpy(), sr) <= TOL
+    else:
+        m0 = (rng.standard_normal((total, dim)) * 0.1).astype(np.float32)
+        v0 = (rng.random((total, dim)) * 0.1).astype(np.float32)
+        md, vd = torch.from_numpy(m0.copy()).to(dev), torch.from_numpy(v0.copy()).to(dev)
+        lr_t = float(oe.adam_lr_t(lr, b1, b2, 3))
+        mr, vr = m0.astype(np.float64), v0.astype(np.float64)
+        if opt == "adam_tf":
+            ops.bwd_apply_adam_tf(plan, g, wd, md, vd, lr_t, b1, b2, eps)
+            oe.apply_adam_tf(wr, mr, vr, grads, lr_t, b1, b2, eps)
+        else:
+            ops.bwd_apply_adam_dense_tf(plan, g, wd, md, vd, lr_t, b1, b2, eps)
+            oe.apply_adam_tf(wr, mr, vr, grads, lr_t, b1, b2, eps, dense=True)
+        assert rel_err(md.cpu().numpy(), mr) <= TOL
+        assert rel_err(vd.cpu().numpy(), vr) <= TOL
+    assert rel_err(wd.cpu().numpy(), wr) <= TOL
+
+
+def test_sparse_update_is_bitwise_reproducible(dev):
+    from recommendation_amd import ops
+    rng = np.random.default_rng(8)
+    dim = 16
+    rows, T, B, L, w, toffs, ids, grad = _bag_problem(rng, dim, "sum")
+    ids[:, 0, :] = rng.integers(0, 3, size=(B, L))
+    outs = []
+    for _ in range(3):
+        plan = ops.SortedPlan(torch.from_numpy(toffs).to(dev), T, int(toffs[-1]), torch.from_numpy(ids).to(dev),
+                              bag_len=L)
+        outs.append(ops.bwd_dense_grad(plan, torch.from_numpy(grad).to(dev), dim, int(toffs[-1])).cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("B,K,N", [(300, 8, 3), (300, 18, 8), (300, 4, 128), (1, 3, 3), (1000, 256, 8)])
+def test_linear_fwd_bwd(dev, B, K, N):
+    from recommendation_amd import ops
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((B, K)).astype(np.float32)
+    W = rng.standard_normal((K, N)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dy = rng.standard_normal((B, N)).astype(np.float32)
+    xd, Wd, bd, dyd = (torch.from_numpy(a).to(dev) for a in (x, W, b, dy))
+    y = ops.linear_fwd(xd, Wd, bd)
+    x64, W64, dy64 = x.astype(np.float64), W.astype(np.float64), dy.astype(np.float64)
+    assert rel_err(y.cpu().numpy(), x64 @ W64 + b) <= RTOL
+    dx, dW, db = ops.linear_bwd(xd, Wd, dyd)
+    assert rel_err(dx.cpu().numpy(), dy64 @ W64.T) <= RTOL
+    assert rel_err(dW.cpu().numpy(), x64.T @ dy64) <= RTOL
+    assert rel_err(db.cpu().numpy(), dy64.sum(0)) <= RTOL
+    assert rel_err(ops.colsum(dyd).cpu().numpy(), dy64.sum(0)) <= RTOL
+
+
+def test_softmax_heads_against_reference_heads(dev):
+    from recommendation_amd import ops
+    rng = np.random.default_rng(10)
+    B, N, k = 300, 128, 6
+    z = (rng.standard_normal((B, N)) * 3).astype(np.float32)
+    z[0, :] = 0.0                      # full tie: top-k must be 0..5
+    z[1, 5] = z[1, 77] = 9.0           # two-way tie at the top: lower index first
+    lab = rng.integers(-1, N, size=B).astype(np.int32)
+    ydense = cm.input_to_one_hot_plus(lab, N)
+    r = ops.softmax_heads(torch.from_numpy(z).to(dev), k=k, labels=torch.from_numpy(ydense).to(dev),
+                          label_ids=torch.from_numpy(lab).to(dev), grad_scale=1.0 / B, want_probs=True,
+                          want_top=True, want_loss=True, want_dlogits=True, want_hits=True)
+    z64 = z.astype(np.float64)
+    assert rel_err(r['probs'].cpu().numpy(), cm.softmax(z64)) <= RTOL
+    idx = r['top_idx'].cpu().numpy()
+    assert idx[0].tolist() == [0, 1, 2, 3, 4, 5]
+    assert idx[1, :2].tolist() == [5, 77]
+    # the device's own probabilities, ranked by the reference rule, must give the device's indices
+    _, want_idx = cm.top_k(r['probs'].cpu().numpy(), k)
+    assert np.array_equal(idx, want_idx)
+    per_row = -(ydense * cm.log_softmax(z64)).sum(axis=1)
+    assert rel_err(r['loss_rows'].cpu().numpy(), per_row) <= RTOL
+    assert rel_err(r['dlogits'].cpu().numpy(), cm.loss_grad_logits(z64, ydense.astype(np.float64))) <= RTOL
+    acc, hits = cm.accuracy(lab, idx, k)
+    assert np.array_equal(r['hit_rows'].cpu().numpy(), hits[:, 0])
+    got_acc = ops.reduce_sum(ops.hit_rows(torch.from_numpy(lab).to(dev), r['top_idx']), 1.0 / B)
+    assert abs(float(got_acc.item()) - float(acc)) <= 1e-6
+    got_loss = ops.reduce_sum(r['loss_rows'], 1.0 / B)
+    assert abs(float(got_loss.item()) - per_row.mean()) <= RTOL * per_row.mean()
+
+
+def test_accuracy_known_answer_from_reference_scratch_file(dev):
+    """recommendation/test.py:19-28 -> per-row hits [1,0,1,0], accuracy 0.5."""
+    from recommendation_amd import ops
+    lab = torch.tensor([5, 2, 9, -1], dtype=torch.int32, device=dev)
+    pred = torch.tensor([[9, 3, 5, 2, 1], [8, 9, 0, 6, 5], [1, 9, 3, 4, 5], [1, 2, 3, 4, 5]], dtype=torch.int32,
+                        device=dev)
+    h = ops.hit_rows(lab, pred)
+    assert h.cpu().numpy().tolist() == [1.0, 0.0, 1.0, 0.0]
+    assert float(ops.reduce_sum(h, 0.25).item()) == 0.5
+
+
+def test_adam_tf_dense(dev):
+    from recommendation_amd import ops
+    rng = np.random.default_rng(11)
+    n = 5910
+    p, m, v, g = (rng.standard_normal(n).astype(np.float32) for _ in range(4))
+    v = np.abs(v)
+    pd, md, vd, gd = (torch.from_numpy(a.copy()).to(dev) for a in (p, m, v, g))
+    lr_t = float(oe.adam_lr_t(1e-4, 0.9, 0.999, 1))
+    ops.adam_tf_dense(pd, md, vd, gd, lr_t, 0.9, 0.999, 1e-8)
+    m64 = 0.9 * m.astype(np.float64) + 0.1 * g
+    v64 = 0.999 * v.astype(np.float64) + 0.001 * g.astype(np.float64) ** 2
+    p64 = p - lr_t * m64 / (np.sqrt(v64) + 1e-8)
+    assert rel_err(md.cpu().numpy(), m64) <= RTOL and rel_err(vd.cpu().numpy(), v64) <= RTOL
+    assert rel_err(pd.cpu().numpy(), p64) <= RTOL
+
+
+@pytest.mark.parametrize("dim", [4, 16, 64, 128])
+@pytest.mark.parametrize("idx_dtype", [np.int32, np.int64])
+def test_fm_forward(dev, dim, idx_dtype):
+    from recommendation_amd import ops
+    rows = [1460, 583, 3000, 305, 24, 3, 10, 4, 18, 15, 105, 27, 2173]
+    st = ofm.State(rows, dim, 13, seed=3)
+    st.bias = np.float32(0.3)
+    B = 515
+    ids, dense, labels = ofm.synthetic_batch(B, rows, 13, seed=4, idx_dtype=idx_dtype)
+    err = ops.new_error_word(dev)
+    r = ops.fm_fwd(torch.from_numpy(st.V).to(dev), torch.from_numpy(st.w1).to(dev),
+                   torch.from_numpy(st.toffs).to(dev), torch.from_numpy(ids).to(dev),
+                   torch.from_numpy(dense).to(dev), torch.from_numpy(st.wd).to(dev),
+                   torch.tensor([st.bias], device=dev), torch.from_numpy(labels).to(dev), 1.0 / B, err)
+    ops.check_error_word(err)
+    z, S, _ = ofm.forward(st.V, st.w1, st.toffs, ids, dense, st.wd, st.bias)
+    per, sig = ofm.bce_with_logits(z, labels.astype(np.float64))
+    assert rel_err(r['S'].cpu().numpy(), S) <= RTOL
+    assert rel_err(r['logit'].cpu().numpy(), z) <= RTOL
+    assert rel_err(r['loss_rows'].cpu().numpy(), per) <= RTOL
+    assert rel_err(r['g'].cpu().numpy(), (sig - labels) / B) <= 2e-5
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad_rowwise", "adam_tf"])
+@pytest.mark.parametrize("dist", ["uniform", "zipf"])
+def test_fm_train_step(dev, opt, dist):
+    """Forward + sorted sparse backward + fused update for 3 steps vs the numpy FM."""
+    from recommendation_amd.fm import FactorizationMachine
+    rows = [1460, 583, 30000, 305, 24, 3, 10, 4, 18, 15, 105, 27, 2173]
+    ref = ofm.State(rows, 16, 13, seed=5, opt=opt)
+    fm = FactorizationMachine(rows, 16, 13, device=dev, opt=opt, lr=1e-2)
+    fm.load_state(ref)
+    B = 2048
+    for step in range(3):
+        ids, dense, labels = ofm.synthetic_batch(B, rows, 13, seed=10 + step, dist=dist)
+        loss = fm.train_step(torch.from_numpy(ids).to(dev), torch.from_numpy(dense).to(dev),
+                             torch.from_numpy(labels).to(dev))
+        want_loss, _ = ofm.train_step(ref, ids, dense, labels, lr=1e-2)
+        assert abs(float(loss.item()) - want_loss) <= 1e-5 * abs(want_loss)
+    # Parameters after 3 steps.  SGD / Adagrad are smooth in the gradient: 1e-5.  Adam's step is
+    # lr_t*m/(sqrt(v)+eps) with eps=1e-8: for the tiny gradients of a mean loss (|g| ~ 1e-4..1e-9)
+    # it amplifies the fp32 rounding of the run sums by up to 0.1/eps, so fp32 (device, and the
+    # TensorFlow reference itself) and the fp64 oracle legitimately differ by ~1e-4*lr per step.
+    tol = 1e-4 if opt == "adam_tf" else 1e-5
+    assert rel_err(fm.V.cpu().numpy(), ref.V) <= tol
+    assert rel_err(fm.w1.cpu().numpy(), ref.w1) <= tol
+    assert rel_err(fm.wd.cpu().numpy(), ref.wd) <= tol
+    assert abs(float(fm.bias.item()) - float(ref.bias)) <= 1e-6
