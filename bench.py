@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: FM training on synthetic Criteo-shaped data.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch already resident in HBM: fused
+gather + FM interaction + loss forward, deterministic sort-by-row, fused sparse
+backward/optimizer, dense-side update.  N = 1: 26 tables (Criteo-Kaggle cardinalities,
+33.76 M rows) x dim 16 fp32, batch 8192, 13 dense features.  N > 1 (launched by
+torch.distributed.run, one rank per GPU): tables sharded row-wise over the ranks, batch
+8192 PER RANK (weak scaling), ids and pooled partial sums exchanged by RCCL all-to-all.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline     the dominant HBM kernel: algorithmic bytes / measured kernel time vs 8 TB/s
+  stages       every stage of the step with its time and algorithmic bytes
+  cpu_baseline the numpy oracle of the same step timed on this host's cores (rank 0, N=1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+CRITEO_KAGGLE = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992,
+                 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=8192, help='batch per GPU')
+    ap.add_argument('--dim', type=int, default=16)
+    ap.add_argument('--opt', default='adam_tf', choices=['sgd', 'adagrad_rowwise', 'adam_tf'])
+    ap.add_argument('--dist', default='uniform', choices=['uniform', 'zipf'])
+    ap.add_argument('--idx-bits', type=int, default=64, choices=[32, 64])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=20)
+    ap.add_argument('--stage-reps', type=int, default=50)
+    return ap.parse_args()
+
+
+def gen_batches(n_batches, B, rows, n_dense, dist, idx_bits, dev, seed):
+    """Synthetic batches generated on the device (torch RNG; shape and distribution as
+    oracle.fm.synthetic_batch): uniform ids or Zipf(1.05) ranks, N(0,1) dense, Bernoulli labels."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    card = torch.tensor(rows, dtype=torch.float64, device=dev)
+    out = []
+    for _ in range(n_batches):
+        u = torch.rand((B, len(rows)), generator=g, dtype=torch.float64, device=dev)
+        if dist == 'uniform':
+            ids = torch.floor(u * card)
+        else:
+            a = 1.0 - 1.05
+            ids = torch.floor(((u * ((card + 1.0) ** a - 1.0)) + 1.0) ** (1.0 / a)) - 1.0
+        ids = torch.minimum(ids.clamp_(min=0), card - 1).to(torch.int64 if idx_bits == 64 else torch.int32)
+        dense = torch.randn((B, n_dense), generator=g, dtype=torch.float32, device=dev)
+        labels = (torch.rand((B,), generator=g, device=dev) < 0.25).to(torch.float32)
+        out.append((ids.contiguous(), dense, labels))
+    return out
+
+
+def time_stage(fn, reps):
+    """Average device time of `fn` in ms: HIP events recorded on the stream the kernels are
+    launched on (torch's current stream), `reps` back-to-back calls between them."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def stage_report(fm, batch, reps, idx_bits):
+    """Per-stage device time and ALGORITHMIC bytes of one FM step at this batch."""
+    from recommendation_amd import ops
+    ids, dense, labels = batch
+    B, T = ids.shape
+    D, nd = fm.dim, fm.n_dense
+    ib = idx_bits // 8
+    r = fm.forward(ids, dense, labels)
+    fm.plan.prepare(ids)
+    torch.cuda.synchronize()
+    U = int(fm.plan.counts[0].item())
+    n_state = {'sgd': 0, 'adagrad_rowwise': 1.0 / D, 'adam_tf': 2}[fm.opt]
+    # bytes (SURVEY formulas): forward = rows + ids + first-order + dense + logit
+    fwd_bytes = B * T * (D * 4 + ib) + B * T * 4 + B * nd * 4 + B * 4
+    # backward/update = per entry S row + perm + g, then read-modify-write of the U distinct rows and state
+    n_state_w1 = {'sgd': 0, 'adagrad_rowwise': 1, 'adam_tf': 2}[fm.opt]
+    bwd_bytes = (B * T * (D * 4 + 8) + U * D * 4 * 2 * (1 + n_state) + U * 4 * 2 * (1 + n_state_w1) + B * 4)
+    passes = -(-int(fm.total_rows).bit_length() // 8)
+    sort_bytes = B * T * (ib + 8) + passes * B * T * 20 + B * T * 16
+    from recommendation_amd.fm import _OPT
+    stages = []
+
+    def add(name, fn, nbytes, kernels):
+        ms = time_stage(fn, reps)
+        stages.append(dict(name=name, ms=round(ms, 5), kernels=kernels, alg_bytes=int(nbytes),
+                           gbs=round(nbytes / ms / 1e6, 1)))
+
+    add('fm_fwd (gather+pool+interaction+loss)', lambda: fm.forward(ids, dense, labels), fwd_bytes, 1)
+    add('sort_by_row (keygen + %d radix passes + runs)' % passes, lambda: fm.plan.prepare(ids), sort_bytes,
+        1 + 3 * passes + 3)
+    # the update stage is timed with lr = 0 so repeated calls do not walk the parameters away
+    add('fm_bwd_apply (segmented sum + fused %s)' % fm.opt,
+        lambda: ops.fm_bwd_apply(fm.plan, r['g'], r['S'], fm.V, fm.w1, _OPT[fm.opt], fm.state, 0.0, fm.beta1,
+                                 fm.beta2, fm.eps), bwd_bytes, 2)
+    add('dense side (dwd/dbias, adam, mean loss)',
+        lambda: (ops.fm_bwd_dense(r['g'], dense, out=fm.dgrad),
+                 ops.adam_tf_dense(fm.dp, fm.dm, fm.dv, fm.dgrad, 0.0, fm.beta1, fm.beta2, fm.eps),
+                 ops.reduce_sum(r['loss_rows'], 1.0 / B, out=fm.loss)), B * (nd + 2) * 4, 3)
+    return stages, U
+
+
+def cpu_baseline(args, rows, fm, batches):
+    """The numpy oracle's FM step (gather formulation) on a bounded sample of the same workload."""
+    from oracle import fm as ofm
+    st = ofm.State.__new__(ofm.State)
+    st.toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    st.V = fm.V.cpu().numpy()
+    st.w1 = fm.w1.cpu().numpy()
+    st.wd = fm.wd.cpu().numpy().copy()
+    st.bias = np.float32(fm.bias.item())
+    st.opt, st.t = args.opt, 0
+    if args.opt == 'adam_tf':
+        st.mV, st.vV = np.zeros_like(st.V), np.zeros_like(st.V)
+        st.mw, st.vw = np.zeros_like(st.w1), np.zeros_like(st.w1)
+    elif args.opt == 'adagrad_rowwise':
+        st.aV, st.aw = np.zeros(st.V.shape[0], np.float32), np.zeros(st.V.shape[0], np.float32)
+    st.md, st.vd = np.zeros(len(st.wd) + 1, np.float32), np.zeros(len(st.wd) + 1, np.float32)
+    host = [(i.cpu().numpy(), d.cpu().numpy(), l.cpu().numpy()) for i, d, l in batches[:4]]
+    ofm.train_step(st, *host[0], lr=1e-3, dtype=np.float32)          # warm
+    t0 = time.perf_counter()
+    n = 0
+    while n < args.cpu_steps and time.perf_counter() - t0 < 30.0:
+        ofm.train_step(st, *host[n % len(host)], lr=1e-3, dtype=np.float32)
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=round(n * args.batch / dt, 1), unit='samples/s', cores=1, kind='port',
+                sample='%d steps of the same workload (batch %d, %d tables x dim %d) through the numpy oracle '
+                       '(gather formulation, fp32, single thread); host has %d cores'
+                       % (n, args.batch, len(rows), args.dim, os.cpu_count() or 0))
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a launcher: python -m torch.distributed.run --nproc-per-node %d "
+                             "bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        torch.distributed.init_process_group('nccl', device_id=dev)
+
+    rows = CRITEO_KAGGLE
+    B = args.batch
+    if world == 1:
+        from recommendation_amd.fm import FactorizationMachine
+        model = FactorizationMachine(rows, args.dim, 13, device=dev, opt=args.opt, lr=1e-3, seed=0)
+    else:
+        from recommendation_amd.sharded import ShardedFactorizationMachine
+        model = ShardedFactorizationMachine(rows, args.dim, 13, device=dev, opt=args.opt, lr=1e-3, seed=0)
+    batches = gen_batches(8, B, rows, 13, args.dist, args.idx_bits, dev, seed=1000 + rank)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        model.train_step(*batches[i % len(batches)])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        model.train_step(*batches[i % len(batches)])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    from recommendation_amd import ops
+    ops.check_error_word(model.err, "bench ids")
+
+    result = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        result = {
+            'metric': 'train_samples_per_sec', 'value': round(B * world * args.steps / dt, 1), 'unit': 'samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'fm_criteo_%dx%d_b%d' % (len(rows), args.dim, B), 'global_batch': B * world,
+                       'tables': len(rows), 'total_rows': int(sum(rows)), 'dim': args.dim, 'n_dense': 13,
+                       'id_bits': args.idx_bits, 'ids': args.dist, 'optimizer': args.opt,
+                       'parallelism': 'single' if world == 1 else 'rowwise-sharded tables x%d + dp dense' % world},
+        }
+    if world == 1:
+        stages, U = stage_report(model, batches[0], args.stage_reps, args.idx_bits)
+        hbm = [s for s in stages if s['name'].startswith(('fm_fwd', 'fm_bwd_apply'))]
+        dom = max(hbm, key=lambda s: s['ms'])
+        result['stages'] = stages
+        result['unique_rows_per_step'] = U
+        result['roofline'] = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS,
+                              'unit': 'GB/s', 'frac': round(dom['gbs'] / HBM_PEAK_GBS, 4), 'traffic': None,
+                              'alg_bytes_per_launch': dom['alg_bytes'], 'ms_per_launch': dom['ms']}
+        emb = [s for s in hbm]
+        result['embedding_hbm_gbs'] = round(sum(s['alg_bytes'] for s in emb) / sum(s['ms'] for s in emb) / 1e6, 1)
+        if not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(args, rows, model, batches)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -19,8 +19,9 @@ itself is not available, so these are pinned by hand-derived known answers):
   log_softmax(z)_ic and the fused kernel's gradient is ``softmax(z) - y``
   whatever the row sum of y is (an all-zero label row still back-propagates
   ``softmax(z)``).
-* ``tf.train.AdamOptimizer``: lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
-  theta -= lr_t * m / (sqrt(v) + eps); applied densely to every variable.
+* ``tf.train.AdamOptimizer`` (the ApplyAdam kernel): alpha = lr*sqrt(1-b2^t)/(1-b1^t);
+  m += (g-m)(1-b1); v += (g^2-v)(1-b2); theta -= m*alpha/(sqrt(v)+eps); applied densely to
+  every variable, the scalars formed in fp32 as the kernel forms them.
 """
 from collections import OrderedDict
 
@@ -322,14 +323,17 @@ class AdamTF(object):
         self.t = 0
 
     def apply(self, params, grads):
+        """TensorFlow's ApplyAdam kernel: m += (g-m)(1-b1); v += (g^2-v)(1-b2);
+        var -= m*alpha/(sqrt(v)+eps), with alpha and (1-beta) as its fp32 arithmetic forms them."""
+        from .embedding import adam_tf_update, tf_adam_scalars
         self.t += 1
-        lr_t = self.lr * np.sqrt(1.0 - self.beta2 ** self.t) / (1.0 - self.beta1 ** self.t)
+        alpha, omb1, omb2 = tf_adam_scalars(self.lr, self.beta1, self.beta2, self.t)
         for n, p in params.items():
             g = grads[n].astype(p.dtype)
             dt = p.dtype.type
-            self.m[n] = dt(self.beta1) * self.m[n] + dt(1.0 - self.beta1) * g
-            self.v[n] = dt(self.beta2) * self.v[n] + dt(1.0 - self.beta2) * g * g
-            p -= dt(lr_t) * self.m[n] / (np.sqrt(self.v[n]) + dt(self.eps))
+            new_p, self.m[n], self.v[n] = adam_tf_update(p, self.m[n], self.v[n], g, dt(alpha), dt(omb1),
+                                                         dt(omb2), dt(self.eps))
+            p[...] = new_p
 
 
 def train_step(params, opt, batch, colour_count=128, recommend_num=6, user_count=100,

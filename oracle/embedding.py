@@ -123,16 +123,37 @@ def apply_adagrad_rowwise(w, state, grads, lr, eps):
         w[r] -= lr * g / (np.sqrt(state[r]) + eps)
 
 
+def tf_adam_scalars(lr, beta1, beta2, t):
+    """The scalars of TensorFlow's ApplyAdam kernel as its fp32 arithmetic yields them:
+    beta1_power / beta2_power are fp32 variables multiplied by beta once per step,
+    alpha = lr*sqrt(1-beta2_power)/(1-beta1_power) and (1-beta) are formed in fp32.
+    ((1 - 0.999f) differs from 0.001 by 1.3e-5 relative: not negligible at the 1e-5 bar.)
+    Returns (alpha, 1-beta1, 1-beta2) as python floats holding fp32 values."""
+    f = np.float32
+    b1p, b2p = f(1.0), f(1.0)
+    for _ in range(int(t)):
+        b1p, b2p = f(b1p * f(beta1)), f(b2p * f(beta2))
+    alpha = f(f(lr) * np.sqrt(f(1.0) - b2p) / (f(1.0) - b1p))
+    return float(alpha), float(f(1.0) - f(beta1)), float(f(1.0) - f(beta2))
+
+
 def adam_lr_t(lr, beta1, beta2, t):
-    return lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    return tf_adam_scalars(lr, beta1, beta2, t)[0]
+
+
+def adam_tf_update(w, m, v, g, alpha, omb1, omb2, eps):
+    """ApplyAdam's three statements: m += (g-m)(1-b1); v += (g^2-v)(1-b2);
+    w -= m*alpha/(sqrt(v)+eps).  Returns the new (w, m, v)."""
+    m = m + (g - m) * omb1
+    v = v + (g * g - v) * omb2
+    return w - (m * alpha) / (np.sqrt(v) + eps), m, v
 
 
 def apply_adam_tf(w, m, v, grads, lr_t, beta1, beta2, eps, dense=False):
     """TensorFlow-form Adam; ``dense`` also decays/moves rows absent from ``grads``."""
     rows = range(w.shape[0]) if dense else grads.keys()
     zero = np.zeros(w.shape[1:], dtype=w.dtype)
+    omb1 = float(np.float32(1.0) - np.float32(beta1))
+    omb2 = float(np.float32(1.0) - np.float32(beta2))
     for r in rows:
-        g = grads.get(r, zero)
-        m[r] = beta1 * m[r] + (1 - beta1) * g
-        v[r] = beta2 * v[r] + (1 - beta2) * g * g
-        w[r] -= lr_t * m[r] / (np.sqrt(v[r]) + eps)
+        w[r], m[r], v[r] = adam_tf_update(w[r], m[r], v[r], grads.get(r, zero), lr_t, omb1, omb2, eps)

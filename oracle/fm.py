@@ -80,7 +80,7 @@ def train_step(st, ids, dense, labels, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8
     g = (sig - labels) / B
     uniq, dV, dw1, dwd, dbias = grads(st.V, st.toffs, ids, dense, g, S, dtype)
     st.t += 1
-    lr_t = emb.adam_lr_t(lr, beta1, beta2, st.t)
+    lr_t, omb1, omb2 = emb.tf_adam_scalars(lr, beta1, beta2, st.t)
     wdt = st.V.dtype
     if st.opt == 'sgd':
         st.V[uniq] -= (lr * dV).astype(wdt)
@@ -92,16 +92,15 @@ def train_step(st, ids, dense, labels, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8
         st.w1[uniq] -= (lr * dw1 / (np.sqrt(st.aw[uniq].astype(dtype)) + eps)).astype(wdt)
     else:
         for w, m, v, gr in ((st.V, st.mV, st.vV, dV), (st.w1, st.mw, st.vw, dw1)):
-            mm = beta1 * m[uniq] + (1 - beta1) * gr
-            vv = beta2 * v[uniq] + (1 - beta2) * gr * gr
-            m[uniq], v[uniq] = mm.astype(wdt), vv.astype(wdt)
-            w[uniq] -= (lr_t * mm / (np.sqrt(vv) + eps)).astype(wdt)
+            nw, mm, vv = emb.adam_tf_update(w[uniq].astype(dtype), m[uniq].astype(dtype), v[uniq].astype(dtype),
+                                            gr, lr_t, omb1, omb2, eps)
+            m[uniq], v[uniq], w[uniq] = mm.astype(wdt), vv.astype(wdt), nw.astype(wdt)
     gd = np.concatenate([dwd, [dbias]])
-    st.md = (beta1 * st.md + (1 - beta1) * gd).astype(wdt)
-    st.vd = (beta2 * st.vd + (1 - beta2) * gd * gd).astype(wdt)
-    upd = lr_t * st.md / (np.sqrt(st.vd) + eps)
-    st.wd -= upd[:-1].astype(wdt)
-    st.bias = wdt.type(st.bias - upd[-1])
+    dp = np.concatenate([st.wd, [st.bias]]).astype(dtype)
+    dp, md, vd = emb.adam_tf_update(dp, st.md.astype(dtype), st.vd.astype(dtype), gd, lr_t, omb1, omb2, eps)
+    st.md, st.vd = md.astype(wdt), vd.astype(wdt)
+    st.wd = dp[:-1].astype(wdt)
+    st.bias = wdt.type(dp[-1])
     return per.mean(), z
 
 

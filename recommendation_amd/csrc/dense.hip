@@ -181,11 +181,12 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, flo
   const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float gi = g[i];
-  const float mi = b1 * m[i] + (1.0f - b1) * gi;
-  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  // TensorFlow's ApplyAdam kernel, statement for statement
+  const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+  const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
   m[i] = mi;
   v[i] = vi;
-  p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  p[i] -= (mi * lr_t) / (sqrtf(vi) + eps);
 }
 
 int splits_for(int64_t B) { return (int) mi_cdiv(B > 0 ? B : 1, ROWS_PER_SPLIT); }

@@ -145,9 +145,10 @@ __device__ __forceinline__ void opt_row(float* w, float* s0, float* s1, int64_t 
     ldv<VEC>(s1 + off, vv);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-      mv[k] = a.beta1 * mv[k] + (1.0f - a.beta1) * g[k];
-      vv[k] = a.beta2 * vv[k] + (1.0f - a.beta2) * g[k] * g[k];
-      wv[k] -= a.lr * mv[k] / (sqrtf(vv[k]) + a.eps);
+      // the three statements of TensorFlow's ApplyAdam kernel, (1 - beta) formed in fp32 as there
+      mv[k] += (g[k] - mv[k]) * (1.0f - a.beta1);
+      vv[k] += (g[k] * g[k] - vv[k]) * (1.0f - a.beta2);
+      wv[k] -= (mv[k] * a.lr) / (sqrtf(vv[k]) + a.eps);
     }
     stv<VEC>(s0 + off, mv);
     stv<VEC>(s1 + off, vv);

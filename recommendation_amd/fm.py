@@ -13,8 +13,6 @@ One training step is five entry points of the C ABI and no torch arithmetic:
   mi_adam_tf_dense     their update; mi_reduce_sum gives the mean loss
 All buffers are allocated once per batch shape, so a step allocates nothing.
 """
-import math
-
 import torch
 
 from . import ops
@@ -48,7 +46,7 @@ class FactorizationMachine(object):
         elif opt == 'adam_tf':
             self.state = [torch.zeros_like(self.V), torch.zeros_like(self.V), torch.zeros_like(self.w1),
                           torch.zeros_like(self.w1)]
-        self.t = 0
+        self._schedule = ops.TFAdamSchedule(lr, beta1, beta2)
         self.err = ops.new_error_word(self.device)
         self._buf_B = None
 
@@ -99,8 +97,7 @@ class FactorizationMachine(object):
         B = ids.shape[0]
         r = self.forward(ids, dense, labels)
         self.plan.prepare(ids)
-        self.t += 1
-        lr_t = self.lr * math.sqrt(1.0 - self.beta2 ** self.t) / (1.0 - self.beta1 ** self.t)
+        lr_t = self._schedule.step()
         lr_sparse = lr_t if self.opt == 'adam_tf' else self.lr
         ops.fm_bwd_apply(self.plan, r['g'], r['S'], self.V, self.w1, _OPT[self.opt], self.state, lr_sparse,
                          self.beta1, self.beta2, self.eps)

@@ -59,6 +59,27 @@ def check_error_word(err, what="ids"):
         raise InvalidArgumentError("%s: %s" % (what, '; '.join(msgs)))
 
 
+class TFAdamSchedule(object):
+    """The scalar side of tf.train.AdamOptimizer as TensorFlow's fp32 arithmetic forms it:
+    beta1_power / beta2_power are fp32 values multiplied by beta once per step and
+    alpha_t = lr*sqrt(1 - beta2_power)/(1 - beta1_power) is evaluated in fp32."""
+
+    def __init__(self, lr, beta1=0.9, beta2=0.999):
+        import numpy as np
+        self._f = np.float32
+        self.lr, self.beta1, self.beta2 = lr, beta1, beta2
+        self.b1p, self.b2p = self._f(1.0), self._f(1.0)
+        self.t = 0
+
+    def step(self):
+        """Advance to the next step and return its alpha_t (a python float holding an fp32 value)."""
+        import numpy as np
+        f = self._f
+        self.t += 1
+        self.b1p, self.b2p = f(self.b1p * f(self.beta1)), f(self.b2p * f(self.beta2))
+        return float(f(f(self.lr) * np.sqrt(f(1.0) - self.b2p) / (f(1.0) - self.b1p)))
+
+
 def table_offsets(rows_per_table, device):
     """int64 [T+1] global row offsets for tables stored back to back."""
     offs = [0]

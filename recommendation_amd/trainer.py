@@ -1,0 +1,98 @@
+"""Train step of the colour model: the arithmetic of the reference's hot loop
+(``recommendation/code/model_trainer.py:138-158,170-174`` and the identical single-process
+``recommendation/local_train_utils.py:33-63``) without the parameter-server cluster around it.
+
+The reference distributes with TensorFlow's asynchronous parameter server (2 workers + 1 ps,
+model_trainer.py:124-136): every variable read and Adam apply is a gRPC hop and workers'
+updates interleave unsynchronised.  Here N ranks run synchronous data parallelism instead:
+each rank takes its own file shard (files[index::parallelism], as the reference does), and the
+flat gradient buffer is all-reduced (mean) before the single fused Adam launch, so all
+replicas hold identical parameters after every step.
+"""
+import torch
+
+from . import ops
+from .r_model import COLUMNS, RecommendationModel, Sample
+
+
+class AdamOptimizer(object):
+    """``tf.train.AdamOptimizer``: alpha_t = lr*sqrt(1-b2^t)/(1-b1^t); m, v dense on every
+    variable; theta -= m*alpha_t/(sqrt(v)+eps) - one launch over the flat parameter buffer."""
+
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.learning_rate, self.beta1, self.beta2, self.epsilon = learning_rate, beta1, beta2, epsilon
+        self.m = self.v = None
+        self._schedule = ops.TFAdamSchedule(learning_rate, beta1, beta2)
+
+    @property
+    def t(self):
+        return self._schedule.t
+
+    def _slots_for(self, params):
+        if self.m is None or self.m.numel() != params.numel():
+            self.m = torch.zeros_like(params, requires_grad=False)
+            self.v = torch.zeros_like(params, requires_grad=False)
+
+    def apply_gradients(self, params, grad):
+        self._slots_for(params)
+        ops.adam_tf_dense(params.detach(), self.m, self.v, grad.contiguous(), self._schedule.step(), self.beta1,
+                          self.beta2, self.epsilon)
+
+    def minimize(self, loss, model, global_step=None, process_group=None):
+        """Backward through the model, (optionally) average gradients over the ranks, update.
+        Returns the new global step."""
+        params = model.parameters()
+        params.grad = None
+        loss.backward()
+        grad = params.grad
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            world = torch.distributed.get_world_size(process_group)
+            if world > 1:
+                torch.distributed.all_reduce(grad, group=process_group)
+                grad = grad / world
+        self.apply_gradients(params, grad)
+        return self.t if global_step is None else global_step + 1
+
+
+def columns_to_features(columns):
+    """The dict the reference builds from the dataset columns (model_trainer.py:142-146)."""
+    features = {k: columns[i] for i, k in enumerate(COLUMNS[:6])}
+    labels = columns[6] if len(columns) > 6 else None
+    return features, labels
+
+
+def train_step(model, optimizer, columns, process_group=None):
+    """One ``mon_sess.run([train_op, acc, labels, top_indices_real, loss, global_step])``
+    (model_trainer.py:147-158, 173-174).  Returns (acc, labels, top_indices, loss, global_step)."""
+    m = model
+    features, labels = columns_to_features(columns)
+    label_tensor = m.input_to_one_hot_plus(labels, m.colour_count)
+    fs = m.features(features)
+    last_layer = m.forward(fs)
+    top_indices, top_values = m.output(last_layer)
+    top_indices_real = top_indices.to(torch.int32)
+    acc = m.accuracy(labels, top_indices_real, m.recommend_num)
+    loss = m.loss(logits=last_layer, labels=label_tensor)
+    global_step = optimizer.minimize(loss, m, process_group=process_group)
+    return acc, labels, top_indices_real, loss.detach(), global_step
+
+
+def train(files, batch_size=300, last_step=5000, learning_rate=1e-4, device='cuda:0', seed=None, parallelism=None,
+          index=None, log_every=100, model=None, process_group=None):
+    """The loop of local_train_utils.train (:30-66) / ModelTrainer.train's worker branch
+    (model_trainer.py:138-179): same model constants, batch size, optimizer and stop step."""
+    m = model or RecommendationModel(colour_count=128, recommend_num=6, user_count=100, country_count=20,
+                                     device=device, seed=seed)
+    dataset = Sample.read_label_data(files, batch_size=batch_size, parallelism=parallelism, index=index)
+    iterator = dataset.make_one_shot_iterator()
+    optimizer = AdamOptimizer(learning_rate=learning_rate)
+    step = 0
+    history = []
+    while step < last_step:
+        columns = iterator.get_next()
+        step += 1
+        acc_res, _, _, loss_res, global_step_res = train_step(m, optimizer, columns, process_group)
+        if log_every and step % log_every == 0:
+            history.append((step, float(loss_res), float(acc_res)))
+            print("Train step %d, loss: %f accuracy: %f" % (step, float(loss_res), float(acc_res)))
+    return m, optimizer, history
