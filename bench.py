@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=20)
     ap.add_argument('--stage-reps', type=int, default=50)
+    ap.add_argument('--no-graph', action='store_true', help='launch the step eagerly instead of replaying a HIP graph')
     return ap.parse_args()
 
 
@@ -88,23 +89,23 @@ def time_stage(fn, reps):
 def stage_report(fm, batch, reps, idx_bits):
     """Per-stage device time and ALGORITHMIC bytes of one FM step at this batch."""
     from recommendation_amd import ops
+    from recommendation_amd.fm import _OPT
     ids, dense, labels = batch
     B, T = ids.shape
     D, nd = fm.dim, fm.n_dense
     ib = idx_bits // 8
     r = fm.forward(ids, dense, labels)
     fm.plan.prepare(ids)
-    torch.cuda.synchronize()
-    U = int(fm.plan.counts[0].item())
+    U = int(ops.SortedPlan(fm.toffs, T, fm.total_rows, ids, bag_len=1).counts[0].item())
     n_state = {'sgd': 0, 'adagrad_rowwise': 1.0 / D, 'adam_tf': 2}[fm.opt]
-    # bytes (SURVEY formulas): forward = rows + ids + first-order + dense + logit
-    fwd_bytes = B * T * (D * 4 + ib) + B * T * 4 + B * nd * 4 + B * 4
-    # backward/update = per entry S row + perm + g, then read-modify-write of the U distinct rows and state
     n_state_w1 = {'sgd': 0, 'adagrad_rowwise': 1, 'adam_tf': 2}[fm.opt]
+    # forward = rows + ids + first-order weights + dense features + logit
+    fwd_bytes = B * T * (D * 4 + ib) + B * T * 4 + B * nd * 4 + B * 4
+    # backward/update = per entry {S row, perm, g}, then read-modify-write of the U distinct rows and their state
     bwd_bytes = (B * T * (D * 4 + 8) + U * D * 4 * 2 * (1 + n_state) + U * 4 * 2 * (1 + n_state_w1) + B * 4)
-    passes = -(-int(fm.total_rows).bit_length() // 8)
-    sort_bytes = B * T * (ib + 8) + passes * B * T * 20 + B * T * 16
-    from recommendation_amd.fm import _OPT
+    bits = int(fm.total_rows).bit_length()
+    passes = -(-bits // 9)
+    sort_bytes = B * T * (ib + 8) + passes * B * T * 20
     stages = []
 
     def add(name, fn, nbytes, kernels):
@@ -113,16 +114,16 @@ def stage_report(fm, batch, reps, idx_bits):
                            gbs=round(nbytes / ms / 1e6, 1)))
 
     add('fm_fwd (gather+pool+interaction+loss)', lambda: fm.forward(ids, dense, labels), fwd_bytes, 1)
-    add('sort_by_row (keygen + %d radix passes + runs)' % passes, lambda: fm.plan.prepare(ids), sort_bytes,
-        1 + 3 * passes + 3)
-    # the update stage is timed with lr = 0 so repeated calls do not walk the parameters away
+    lds_sort = B <= 8192
+    add('sort_by_row (%s)' % ('per-table LDS sort, 1 launch' if lds_sort else 'keygen + %d radix passes' % passes),
+        lambda: fm.plan.prepare(ids), sort_bytes, 1 if lds_sort else 1 + 3 * passes)
+    # the update stages are timed with lr = 0 so repeated calls do not walk the parameters away
     add('fm_bwd_apply (segmented sum + fused %s)' % fm.opt,
-        lambda: ops.fm_bwd_apply(fm.plan, r['g'], r['S'], fm.V, fm.w1, _OPT[fm.opt], fm.state, 0.0, fm.beta1,
-                                 fm.beta2, fm.eps), bwd_bytes, 2)
-    add('dense side (dwd/dbias, adam, mean loss)',
-        lambda: (ops.fm_bwd_dense(r['g'], dense, out=fm.dgrad),
-                 ops.adam_tf_dense(fm.dp, fm.dm, fm.dv, fm.dgrad, 0.0, fm.beta1, fm.beta2, fm.eps),
-                 ops.reduce_sum(r['loss_rows'], 1.0 / B, out=fm.loss)), B * (nd + 2) * 4, 3)
+        lambda: ops.fm_bwd_apply(fm.plan, fm.table, r['g'], r['S'], _OPT[fm.opt], 0.0, fm.beta1, fm.beta2, fm.eps),
+        bwd_bytes, 2)
+    add('dense side (dwd/dbias + adam + mean loss)',
+        lambda: ops.fm_dense_step(r['g'], dense, r['loss_rows'], fm.dp, fm.dm, fm.dv, 0.0, fm.beta1, fm.beta2,
+                                  fm.eps, fm.loss), B * (nd + 2) * 4, 1)
     return stages, U
 
 
@@ -131,8 +132,8 @@ def cpu_baseline(args, rows, fm, batches):
     from oracle import fm as ofm
     st = ofm.State.__new__(ofm.State)
     st.toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
-    st.V = fm.V.cpu().numpy()
-    st.w1 = fm.w1.cpu().numpy()
+    st.V = fm.V.contiguous().cpu().numpy()
+    st.w1 = fm.w1.contiguous().cpu().numpy()
     st.wd = fm.wd.cpu().numpy().copy()
     st.bias = np.float32(fm.bias.item())
     st.opt, st.t = args.opt, 0
@@ -186,12 +187,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        model.train_step(*batches[i % len(batches)])
+    use_graph = (world == 1) and not args.no_graph
+    kw = {'graph': True} if use_graph else {}
+    for i in range(max(args.warmup, len(batches) if use_graph else 0)):   # every batch's graph captured before timing
+        model.train_step(*batches[i % len(batches)], **kw)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        model.train_step(*batches[i % len(batches)])
+        model.train_step(*batches[i % len(batches)], **kw)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -211,6 +214,7 @@ def main():
             'config': {'workload': 'fm_criteo_%dx%d_b%d' % (len(rows), args.dim, B), 'global_batch': B * world,
                        'tables': len(rows), 'total_rows': int(sum(rows)), 'dim': args.dim, 'n_dense': 13,
                        'id_bits': args.idx_bits, 'ids': args.dist, 'optimizer': args.opt,
+                       'launch': 'hip graph replay' if use_graph else 'eager',
                        'parallelism': 'single' if world == 1 else 'rowwise-sharded tables x%d + dp dense' % world},
         }
     if world == 1:

@@ -99,6 +99,11 @@ int mi_validate_ids(const int64_t* table_offsets, int T, const void* indices, in
  *                           [n_unique] = n_valid
  *   counts[2]       int32   {n_unique, n_valid}
  * These are the bit-exact artefacts (== numpy stable argsort / unique).
+ * unique_rows, seg_offsets and counts may ALL be NULL: run detection (three launches) is
+ * then skipped and the apply calls find the runs in sorted_rows themselves.  In that form,
+ * with fixed-width bags of at most 8192 entries per table, the whole sort is ONE launch
+ * (each table sorted in the LDS of one CU) and padding / invalid entries end their TABLE's
+ * block of sorted_rows (as the value total_rows) instead of the whole array.
  * No reference counterpart: TensorFlow's MatMul gradient builds the dense [V,D] gradient
  * (model_trainer.py:157-158); this is its sparse equivalent.
  * ---------------------------------------------------------------------------------- */
@@ -112,7 +117,7 @@ int mi_embag_bwd_prepare(const int64_t* table_offsets, int T, int64_t total_rows
 
 /* Generic stable key/value radix sort used by the above (exported for tests).
  * keys/vals are overwritten with the sorted result; key_bits = number of low bits that
- * differ (passes = ceil(key_bits/8)). */
+ * differ (passes = ceil(key_bits/9), 8- or 9-bit digits). */
 int mi_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int key_bits,
                       void* workspace, size_t workspace_bytes, void* stream);
 
@@ -121,21 +126,24 @@ int mi_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int key_bits,
  * grad_out[(i/T)*grad_ld + (i%T)*dim + d] is dL/d(pooled output of bag i); an entry of a
  * mean-pooled bag receives it divided by the bag's count of non-padding ids.
  * The gradient of distinct row r is the sum over its run, taken in a fixed order
- * (deterministic, no atomics).  `long_list` is int32 scratch of n_entries+1 ints.
+ * (deterministic, no atomics).  `long_list` is int32 scratch of n_entries+2 ints whose
+ * first two ints the caller zeroes ONCE after allocating it; every call leaves them zero
+ * again (two calls sharing one long_list must not overlap in time).
  * ---------------------------------------------------------------------------------- */
 typedef struct mi_bwd_plan {
   const uint32_t* sorted_rows;
   const int32_t* perm;
-  const uint32_t* unique_rows;
+  const uint32_t* unique_rows; /* these three: all set, or all NULL (see mi_embag_bwd_prepare) */
   const int32_t* seg_offsets;
   const int32_t* counts;  /* {n_unique, n_valid} on device */
   int64_t n_entries;      /* capacity (upper bound of n_valid) */
   int64_t n_bags;
+  int64_t total_rows;     /* as given to mi_embag_bwd_prepare */
   const int64_t* offsets; /* CSR offsets or NULL */
   int bag_len;
   int T;
   int pool_mode;
-  int32_t* long_list; /* scratch, n_entries + 1 ints */
+  int32_t* long_list; /* scratch, n_entries + 2 ints, first two zeroed once by the caller */
   /* needed for MI_POOL_MEAN only (the bag's count of valid ids); may be NULL for sum */
   const void* indices;
   int idx_bits;
@@ -215,31 +223,67 @@ int mi_adam_tf_dense(float* p, float* m, float* v, const float* g, int64_t n, fl
  * FM (not in the reference; extension named by the benchmark definition).
  * logit[b] = bias + sum_f w1[row(b,f)] + sum_j wd[j]*dense[b][j]
  *            + 0.5 * sum_k ( (sum_f V[row(b,f)][k])^2 - sum_f V[row(b,f)][k]^2 )
- * one id per field: ids[B][T].  Also emits S[b][k] = sum_f V[row][k] (kept for backward),
- * and, when labels != NULL, BCE-with-logits loss rows and g[b] = (sigmoid(logit)-y)*gscale.
+ * one id per field: ids[B][T].
+ *
+ * HBM layout: one RECORD per global row holding everything a step touches for that row -
+ * the embedding V[dim], the first-order weight w1 and the optimizer state of both - so the
+ * forward reads one 128-byte line per (sample, field) and the update reads and writes one
+ * or two lines per distinct row, instead of six scattered lines across separate arrays.
+ *   rec[row*stride + 0 .. dim)        V
+ *   rec[row*stride + off_w1]          w1
+ *   rec[row*stride + off_vs0 ..]      V state 0: Adagrad row accumulator (1 float) | Adam m[dim]
+ *   rec[row*stride + off_vs1 ..]      V state 1: Adam v[dim]
+ *   rec[row*stride + off_ws0/off_ws1] w1 state (1 float each)
+ * stride is a multiple of 4 floats and rec is 16-byte aligned (128-byte records recommended);
+ * vector offsets (off_vs0/off_vs1 under Adam) are multiples of 4.  Unused offsets are ignored.
  * ---------------------------------------------------------------------------------- */
-int mi_fm_fwd(const float* V, const float* w1, const int64_t* table_offsets, int T, int dim,
-              const void* ids, int idx_bits, int64_t B, const float* dense, int n_dense,
-              const float* wd, const float* bias, const float* labels, float gscale,
-              float* logit, float* S, float* loss_rows, float* g, int32_t* err, void* stream);
+typedef struct mi_fm_table {
+  float* rec;
+  int64_t stride;
+  int dim;
+  int off_w1;
+  int off_vs0, off_vs1;
+  int off_ws0, off_ws1;
+} mi_fm_table;
 
 #define MI_OPT_SGD 0
 #define MI_OPT_ADAGRAD_ROWWISE 1
 #define MI_OPT_ADAM_TF 2
 
+/* Forward.  Also emits S[b][k] = sum_f V[row][k] (kept for backward) and, when labels !=
+ * NULL, BCE-with-logits loss rows and g[b] = (sigmoid(logit)-y)*gscale. */
+int mi_fm_fwd(const mi_fm_table* tab, const int64_t* table_offsets, int T, const void* ids,
+              int idx_bits, int64_t B, const float* dense, int n_dense, const float* wd,
+              const float* bias, const float* labels, float gscale, float* logit, float* S,
+              float* loss_rows, float* g, int32_t* err, void* stream);
+
 /* FM backward fused with the sparse update of V and w1.  For distinct row r with run
  * {b_i}: dV[r] = sum_i g[b_i]*S[b_i] - V[r]*sum_i g[b_i];  dw1[r] = sum_i g[b_i].
- * plan comes from mi_embag_bwd_prepare on ids (bag_len 1).  State buffers by optimizer:
- *   SGD: none;  ADAGRAD_ROWWISE: st0 = accV[total_rows], st1 = accw1[total_rows];
- *   ADAM_TF: st0 = mV, st1 = vV ([total_rows][dim]), st2 = mw1, st3 = vw1 ([total_rows]). */
-int mi_fm_bwd_apply(const mi_bwd_plan* plan, const float* g, const float* S, int dim, float* V,
-                    float* w1, int opt, float* st0, float* st1, float* st2, float* st3,
-                    float lr, float beta1, float beta2, float eps, void* stream);
+ * plan comes from mi_embag_bwd_prepare on ids (bag_len 1); its run arrays may be NULL.
+ * lr is alpha_t for MI_OPT_ADAM_TF (see mi_adam_tf_dense); when lr_dev != NULL the step
+ * size is read from lr_dev[0] on the device instead (see mi_adam_schedule_step), which lets a
+ * captured HIP graph be replayed step after step. */
+int mi_fm_bwd_apply(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* g,
+                    const float* S, int opt, float lr, const float* lr_dev, float beta1,
+                    float beta2, float eps, void* stream);
 
 /* Dense-side FM gradients: dwd[j] = sum_b g[b]*dense[b][j], dbias = sum_b g[b]
  * (fixed-order sums).  out = dwd[n_dense] followed by dbias. */
 int mi_fm_bwd_dense(const float* g, const float* dense, int n_dense, int64_t B, float* out,
                     void* stream);
+
+/* The whole dense side of an FM step in ONE launch: the gradients above, TensorFlow-form
+ * Adam on dp = {wd[n_dense], bias} with state dm/dv, and loss_out[0] = mean(loss_rows). */
+int mi_fm_dense_step(const float* g, const float* dense, int n_dense, int64_t B,
+                     const float* loss_rows, float* dp, float* dm, float* dv, float lr_t,
+                     const float* lr_dev, float beta1, float beta2, float eps, float* loss_out,
+                     void* stream);
+
+/* tf.train.AdamOptimizer's scalar state kept on the device, as TensorFlow keeps it
+ * (model_trainer.py:157): sched = {alpha_t, beta1_power, beta2_power}, initialised by the
+ * caller to {0, 1, 1}.  One call = one optimizer step: both powers are multiplied by their
+ * beta and alpha_t = lr*sqrt(1-beta2_power)/(1-beta1_power), all in fp32. */
+int mi_adam_schedule_step(float* sched, float lr, float beta1, float beta2, void* stream);
 
 #ifdef __cplusplus
 }

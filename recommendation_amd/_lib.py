@@ -26,10 +26,16 @@ class BwdPlan(Structure):
     _fields_ = [
         ('sorted_rows', c_void_p), ('perm', c_void_p), ('unique_rows', c_void_p),
         ('seg_offsets', c_void_p), ('counts', c_void_p),
-        ('n_entries', c_int64), ('n_bags', c_int64), ('offsets', c_void_p),
+        ('n_entries', c_int64), ('n_bags', c_int64), ('total_rows', c_int64), ('offsets', c_void_p),
         ('bag_len', c_int), ('T', c_int), ('pool_mode', c_int), ('long_list', c_void_p),
         ('indices', c_void_p), ('idx_bits', c_int), ('table_offsets', c_void_p),
     ]
+
+
+class FmTable(Structure):
+    """struct mi_fm_table"""
+    _fields_ = [('rec', c_void_p), ('stride', c_int64), ('dim', c_int), ('off_w1', c_int), ('off_vs0', c_int),
+                ('off_vs1', c_int), ('off_ws0', c_int), ('off_ws1', c_int)]
 
 
 P = c_void_p
@@ -59,10 +65,13 @@ _SIGNATURES = {
     'mi_colsum': (c_int, [P, c_int64, c_int64, c_int, P, P]),
     'mi_reduce_sum': (c_int, [P, c_int64, c_float, P, P]),
     'mi_adam_tf_dense': (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P]),
-    'mi_fm_fwd': (c_int, [P, P, P, c_int, c_int, P, c_int, c_int64, P, c_int, P, P, P, c_float, P, P, P, P, P, P]),
-    'mi_fm_bwd_apply': (c_int, [POINTER(BwdPlan), P, P, c_int, P, P, c_int, P, P, P, P, c_float, c_float, c_float,
+    'mi_fm_fwd': (c_int, [POINTER(FmTable), P, c_int, P, c_int, c_int64, P, c_int, P, P, P, c_float, P, P, P, P, P,
+                          P]),
+    'mi_fm_bwd_apply': (c_int, [POINTER(BwdPlan), POINTER(FmTable), P, P, c_int, c_float, P, c_float, c_float,
                                 c_float, P]),
     'mi_fm_bwd_dense': (c_int, [P, P, c_int, c_int64, P, P]),
+    'mi_fm_dense_step': (c_int, [P, P, c_int, c_int64, P, P, P, P, c_float, P, c_float, c_float, c_float, P, P]),
+    'mi_adam_schedule_step': (c_int, [P, c_float, c_float, c_float, P]),
 }
 
 EXPORTS = tuple(sorted(_SIGNATURES))

@@ -9,6 +9,7 @@
 #define MI_WAVE 64
 
 void mi_set_error(const char* fmt, ...);
+int mi_fm_check_table(const mi_fm_table* t, int opt, const char* who);
 
 #define MI_REQUIRE(cond, ...)        \
   do {                               \

@@ -6,29 +6,52 @@
 // for every distinct row, the list of entries that touched it, in a reproducible order:
 // that list is what this file produces (== numpy's stable argsort + unique).
 //
-// Radix sort, 8 bits per pass, three launches per pass:
-//   hist    : per-tile digit histogram (LDS integer atomics: order-independent counts)
-//   scan    : exclusive scan of the digit-major [256][tiles] table (one workgroup)
-//   scatter : per tile, stable rank of every key among equal digits (wave-level digit
-//             matching by ballots, wave64), plus the scanned base -> final position.
+// Radix sort, 8- or 9-bit digits, three launches per pass:
+//   hist       : per-tile digit histogram (LDS integer atomics: order-independent counts)
+//   digit_scan : one workgroup per digit scans that digit's per-tile counts (a contiguous
+//                row of the digit-major [radix][tiles] table) and stores the digit total
+//   scatter    : per tile, stable rank of every key among equal digits (wave-level digit
+//                matching by ballots, wave64) + digit base + tile offset -> final position.
 // Keys are uint32; a pass costs 4+4 B read and 4+4 B written per pair for scatter and
 // 4 B read for hist: 20 B per pair per pass.
 #include "common.h"
 
 namespace {
 
-constexpr int RADIX_BITS = 8;
-constexpr int RADIX = 1 << RADIX_BITS;
 constexpr int SORT_BLOCK = 256;
 constexpr int SORT_WAVES = SORT_BLOCK / MI_WAVE;
-constexpr int ITEMS = 8;
-constexpr int TILE = SORT_BLOCK * ITEMS;  // 2048 pairs per workgroup
+constexpr int SMALL_N = 1 << 19;  // up to here: 4 pairs per thread (1024 per workgroup), else 8 (2048)
+constexpr int MAX_RADIX = 512;
 constexpr int SCAN_BLOCK = 1024;
 
+// inclusive scan over the 256 threads of a workgroup; `total` gets the workgroup sum
+__device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* wsum /*[4]*/, uint32_t& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();  // wsum may still be read from a previous call
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+#pragma unroll
+  for (int i = 0; i < SORT_WAVES; ++i) {
+    if (i < w) base += wsum[i];
+  }
+  total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  return base + inc;
+}
+
+template <int RB, int ITEMS>
 __global__ __launch_bounds__(SORT_BLOCK) void hist_kernel(const uint32_t* __restrict__ keys, int n, int shift,
                                                          uint32_t* __restrict__ hist, int tiles) {
+  constexpr int RADIX = 1 << RB;
+  constexpr int TILE = SORT_BLOCK * ITEMS;
   __shared__ uint32_t h[RADIX];
-  h[threadIdx.x] = 0;
+  for (int d = threadIdx.x; d < RADIX; d += SORT_BLOCK) h[d] = 0;
   __syncthreads();
   const int base = blockIdx.x * TILE;
 #pragma unroll
@@ -37,72 +60,73 @@ __global__ __launch_bounds__(SORT_BLOCK) void hist_kernel(const uint32_t* __rest
     if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & (RADIX - 1)], 1u);
   }
   __syncthreads();
-  hist[(size_t) threadIdx.x * tiles + blockIdx.x] = h[threadIdx.x];
+  for (int d = threadIdx.x; d < RADIX; d += SORT_BLOCK) hist[(size_t) d * tiles + blockIdx.x] = h[d];
 }
 
-// Exclusive scan of `total` uint32 in place by ONE workgroup; optionally also stores the
-// grand total.
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_kernel(uint32_t* __restrict__ data, int total,
-                                                         uint32_t* __restrict__ grand_total) {
-  __shared__ uint32_t wsum[SCAN_BLOCK / MI_WAVE];
-  const int tid = threadIdx.x;
-  const int chunk = (total + SCAN_BLOCK - 1) / SCAN_BLOCK;
-  const int beg = min(tid * chunk, total);
-  const int end = min(beg + chunk, total);
-  uint32_t s = 0;
-  for (int i = beg; i < end; ++i) s += data[i];
-  // inclusive scan across the wave
-  const int lane = tid & 63, w = tid >> 6;
-  uint32_t inc = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
+// One workgroup per digit: exclusive scan of that digit's per-tile counts (a contiguous,
+// coalesced row of the digit-major table), and the digit's total.
+__global__ __launch_bounds__(SORT_BLOCK) void digit_scan_kernel(uint32_t* __restrict__ hist, int tiles,
+                                                               uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wsum[SORT_WAVES];
+  uint32_t* row = hist + (size_t) blockIdx.x * tiles;
+  uint32_t carry = 0;
+  for (int base = 0; base < tiles; base += SORT_BLOCK) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = i < tiles ? row[i] : 0u;
+    uint32_t total;
+    const uint32_t inc = block_inclusive_scan(v, wsum, total);
+    if (i < tiles) row[i] = carry + inc - v;
+    carry += total;
   }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  if (w == 0) {
-    uint32_t v = (lane < SCAN_BLOCK / MI_WAVE) ? wsum[lane] : 0;
-    uint32_t vi = v;
-#pragma unroll
-    for (int o = 1; o < SCAN_BLOCK / MI_WAVE; o <<= 1) {
-      const uint32_t t = __shfl_up(vi, o, 64);
-      if (lane >= o) vi += t;
-    }
-    if (lane < SCAN_BLOCK / MI_WAVE) wsum[lane] = vi - v;  // exclusive wave base
-    if (lane == SCAN_BLOCK / MI_WAVE - 1 && grand_total) *grand_total = vi;
-  }
-  __syncthreads();
-  uint32_t run = wsum[w] + inc - s;
-  for (int i = beg; i < end; ++i) {
-    const uint32_t t = data[i];
-    data[i] = run;
-    run += t;
-  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+template <int RB, int ITEMS>
 __global__ __launch_bounds__(SORT_BLOCK) void scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                             const uint32_t* __restrict__ vals_in,
                                                             uint32_t* __restrict__ keys_out,
                                                             uint32_t* __restrict__ vals_out, int n, int shift,
-                                                            const uint32_t* __restrict__ hist, int tiles) {
+                                                            const uint32_t* __restrict__ hist, int tiles,
+                                                            const uint32_t* __restrict__ totals) {
+  constexpr int RADIX = 1 << RB;
+  constexpr int PER = RADIX / SORT_BLOCK;  // digits owned by one thread (consecutive)
+  constexpr int TILE = SORT_BLOCK * ITEMS;
   __shared__ uint32_t cnt[SORT_WAVES][RADIX];
+  __shared__ uint32_t wsum[SORT_WAVES];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int d = tid; d < RADIX; d += SORT_BLOCK) {
 #pragma unroll
-  for (int i = 0; i < SORT_WAVES; ++i) cnt[i][tid] = 0;
-  __syncthreads();
+    for (int i = 0; i < SORT_WAVES; ++i) cnt[i][d] = 0;
+  }
+  // every global load this workgroup needs is issued up front: its pairs, the digit totals and
+  // this tile's offsets (one memory round trip, not three)
   const int wbase = blockIdx.x * TILE + w * (MI_WAVE * ITEMS);
+  uint32_t key[ITEMS], val[ITEMS], loc[ITEMS];
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const int idx = wbase + j * MI_WAVE + lane;
+    key[j] = idx < n ? keys_in[idx] : 0xFFFFFFFFu;
+    val[j] = idx < n ? vals_in[idx] : 0u;
+  }
+  uint32_t tot[PER], toff[PER], tsum = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    tot[q] = totals[tid * PER + q];
+    toff[q] = hist[(size_t) (tid * PER + q) * tiles + blockIdx.x];
+    tsum += tot[q];
+  }
+  // digit bases = exclusive scan of the digit totals (every workgroup redoes this small scan)
+  uint32_t grand;
+  uint32_t dbase = block_inclusive_scan(tsum, wsum, grand) - tsum;  // also orders the cnt[] zeroing
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  uint32_t key[ITEMS], loc[ITEMS];
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
     const int idx = wbase + j * MI_WAVE + lane;
     const bool valid = idx < n;
-    key[j] = valid ? keys_in[idx] : 0xFFFFFFFFu;
     const uint32_t d = (key[j] >> shift) & (RADIX - 1);
     unsigned long long mask = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < RADIX_BITS; ++b) {
+    for (int b = 0; b < RB; ++b) {
       const bool bit = (d >> b) & 1u;
       const unsigned long long bal = __ballot(bit);
       mask &= bit ? bal : ~bal;
@@ -113,13 +137,16 @@ __global__ __launch_bounds__(SORT_BLOCK) void scatter_kernel(const uint32_t* __r
     loc[j] = old + before;
   }
   __syncthreads();
-  {
-    // digit `tid`: global base of this tile, then running base per wave
-    uint32_t run = hist[(size_t) tid * tiles + blockIdx.x];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    // digit d: base of the digit + this tile's offset inside it, then a running base per wave
+    const int d = tid * PER + q;
+    uint32_t run = dbase + toff[q];
+    dbase += tot[q];
 #pragma unroll
     for (int i = 0; i < SORT_WAVES; ++i) {
-      const uint32_t t = cnt[i][tid];
-      cnt[i][tid] = run;
+      const uint32_t t = cnt[i][d];
+      cnt[i][d] = run;
       run += t;
     }
   }
@@ -131,7 +158,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void scatter_kernel(const uint32_t* __r
       const uint32_t d = (key[j] >> shift) & (RADIX - 1);
       const uint32_t pos = cnt[w][d] + loc[j];
       keys_out[pos] = key[j];
-      vals_out[pos] = vals_in[idx];
+      vals_out[pos] = val[j];
     }
   }
 }
@@ -140,42 +167,74 @@ struct SortWs {
   uint32_t* keys_alt;
   uint32_t* vals_alt;
   uint32_t* hist;
+  uint32_t* totals;
   uint32_t* seg_blocks;  // per-block head counts, then valid counts
   int tiles;
 };
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t) 255; }
 
+int items_for(int64_t n) { return n <= SMALL_N ? 4 : 8; }
+int64_t tiles_for(int64_t n) { return mi_cdiv(n > 0 ? n : 1, (int64_t) SORT_BLOCK * items_for(n)); }
+
 size_t sort_ws_bytes(int64_t n) {
-  const int64_t tiles = mi_cdiv(n > 0 ? n : 1, TILE);
-  return align256((size_t) n * 4) * 2 + align256((size_t) RADIX * tiles * 4) + align256((size_t) (2 * tiles + 2) * 4);
+  const int64_t tiles = tiles_for(n);
+  return align256((size_t) n * 4) * 2 + align256((size_t) MAX_RADIX * tiles * 4) + align256(MAX_RADIX * 4) +
+         align256((size_t) (2 * tiles + 2) * 4);
 }
 
 SortWs carve(void* ws, int64_t n) {
   SortWs s;
   char* p = (char*) ws;
-  s.tiles = (int) mi_cdiv(n > 0 ? n : 1, TILE);
+  s.tiles = (int) tiles_for(n);
   s.keys_alt = (uint32_t*) p;
   p += align256((size_t) n * 4);
   s.vals_alt = (uint32_t*) p;
   p += align256((size_t) n * 4);
   s.hist = (uint32_t*) p;
-  p += align256((size_t) RADIX * s.tiles * 4);
+  p += align256((size_t) MAX_RADIX * s.tiles * 4);
+  s.totals = (uint32_t*) p;
+  p += align256(MAX_RADIX * 4);
   s.seg_blocks = (uint32_t*) p;
   return s;
 }
 
-// Sorts (keys, vals); result ends in (keys, vals).
-int radix_sort(uint32_t* keys, uint32_t* vals, int n, int key_bits, const SortWs& ws, hipStream_t s) {
-  if (n <= 1) return MI_OK;
-  const int passes = (int) mi_cdiv(key_bits > 0 ? key_bits : 1, RADIX_BITS);
+// digits of 8 bits, or 9 where that saves a whole pass (e.g. 26-bit rows: 3 passes, not 4)
+void pass_plan(int key_bits, int* passes, int* rb) {
+  if (key_bits < 1) key_bits = 1;
+  *passes = (int) mi_cdiv(key_bits, 9);
+  *rb = mi_cdiv(key_bits, *passes) <= 8 ? 8 : 9;
+}
+
+template <int RB, int ITEMS>
+void launch_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, int n, int shift,
+                 const SortWs& ws, hipStream_t s) {
+  hipLaunchKernelGGL((hist_kernel<RB, ITEMS>), dim3(ws.tiles), dim3(SORT_BLOCK), 0, s, ki, n, shift, ws.hist,
+                     ws.tiles);
+  hipLaunchKernelGGL(digit_scan_kernel, dim3(1 << RB), dim3(SORT_BLOCK), 0, s, ws.hist, ws.tiles, ws.totals);
+  hipLaunchKernelGGL((scatter_kernel<RB, ITEMS>), dim3(ws.tiles), dim3(SORT_BLOCK), 0, s, ki, vi, ko, vo, n, shift,
+                     ws.hist, ws.tiles, ws.totals);
+}
+
+// Sorts (keys, vals); result ends in (keys, vals).  With `input_in_alt` the caller has put the
+// unsorted pairs in the workspace's alternate buffers instead (it does so when the number of
+// passes is odd, which makes the last pass land in (keys, vals) without a copy).
+int radix_sort(uint32_t* keys, uint32_t* vals, int n, int key_bits, const SortWs& ws, hipStream_t s,
+               bool input_in_alt = false) {
+  if (n <= 1 && !input_in_alt) return MI_OK;
+  int passes, rb;
+  pass_plan(key_bits, &passes, &rb);
   uint32_t *ki = keys, *vi = vals, *ko = ws.keys_alt, *vo = ws.vals_alt;
+  if (input_in_alt) { ki = ws.keys_alt; vi = ws.vals_alt; ko = keys; vo = vals; }
   for (int p = 0; p < passes; ++p) {
-    const int shift = p * RADIX_BITS;
-    hipLaunchKernelGGL(hist_kernel, dim3(ws.tiles), dim3(SORT_BLOCK), 0, s, ki, n, shift, ws.hist, ws.tiles);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws.hist, RADIX * ws.tiles, (uint32_t*) nullptr);
-    hipLaunchKernelGGL(scatter_kernel, dim3(ws.tiles), dim3(SORT_BLOCK), 0, s, ki, vi, ko, vo, n, shift, ws.hist,
-                       ws.tiles);
+    const bool small = items_for(n) == 4;
+    if (rb == 8) {
+      if (small) launch_pass<8, 4>(ki, vi, ko, vo, n, p * rb, ws, s);
+      else launch_pass<8, 8>(ki, vi, ko, vo, n, p * rb, ws, s);
+    } else {
+      if (small) launch_pass<9, 4>(ki, vi, ko, vo, n, p * rb, ws, s);
+      else launch_pass<9, 8>(ki, vi, ko, vo, n, p * rb, ws, s);
+    }
     uint32_t* t = ki; ki = ko; ko = t;
     t = vi; vi = vo; vo = t;
   }
@@ -331,6 +390,132 @@ __global__ __launch_bounds__(256) void seg_write_kernel(const uint32_t* __restri
   }
 }
 
+// ---- per-table sort in LDS -------------------------------------------------------------------
+// With fixed-width bags every table receives the same number of entries, B*bag_len.  When that
+// is at most TS_MAX the whole sort of a table fits the LDS of one CU (two key/value images of
+// 64 KB): ONE launch, one workgroup per table, all radix passes on chip, and each table only
+// makes the passes its own row count needs (a table of 3 rows: one pass; 10 M rows: three).
+// Tables are laid out back to back in row order, so concatenating the per-table results IS the
+// global sort by (row, position); padding / invalid entries end each table's block as sentinels.
+constexpr int TS_THREADS = 1024;
+constexpr int TS_WAVES = TS_THREADS / MI_WAVE;
+constexpr int TS_ITEMS = 8;
+constexpr int TS_MAX = TS_THREADS * TS_ITEMS;  // 8192 entries per table
+constexpr int TS_RADIX = 256;
+
+template <typename IDX>
+__global__ __launch_bounds__(TS_THREADS) void table_sort_kernel(const int64_t* __restrict__ toffs, int T,
+                                                               const void* __restrict__ indices, int bag_len,
+                                                               int n, uint32_t sentinel,
+                                                               uint32_t* __restrict__ sorted_rows,
+                                                               uint32_t* __restrict__ perm) {
+  __shared__ uint32_t kbuf[2][TS_MAX];
+  __shared__ uint32_t vbuf[2][TS_MAX];
+  __shared__ uint32_t cnt[TS_WAVES][TS_RADIX];
+  __shared__ uint32_t dbase[TS_RADIX];
+  __shared__ uint32_t wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int t = blockIdx.x;
+  const int64_t base_row = toffs[t];
+  const uint32_t rows = (uint32_t) (toffs[t + 1] - base_row);
+  // local key: the id, or `rows` (one past the largest) for a padding / out-of-range entry
+#pragma unroll
+  for (int k = 0; k < TS_ITEMS; ++k) {
+    const int e = k * TS_THREADS + tid;
+    if (e < n) {
+      const int b = e / bag_len;
+      const int p = (b * T + t) * bag_len + (e - b * bag_len);
+      const int64_t id = mi_ld_id<IDX>(indices, p);
+      kbuf[0][e] = (id >= 0 && id < (int64_t) rows) ? (uint32_t) id : rows;
+      vbuf[0][e] = (uint32_t) p;
+    }
+  }
+  int bits = 0;
+  for (uint32_t v = rows; v; v >>= 1) ++bits;  // values 0..rows
+  const int passes = (bits + 7) / 8;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int cur = 0;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = pass * 8;
+    for (int i = tid; i < TS_WAVES * TS_RADIX; i += TS_THREADS) (&cnt[0][0])[i] = 0;
+    __syncthreads();  // also covers the initial fill / the previous pass's scatter
+    // rank inside the wave's 512-entry slice (entry j of lane l: slice + j*64 + l)
+    uint32_t key[TS_ITEMS], loc[TS_ITEMS];
+    const int wbase = w * (MI_WAVE * TS_ITEMS);
+#pragma unroll
+    for (int j = 0; j < TS_ITEMS; ++j) {
+      const int e = wbase + j * MI_WAVE + lane;
+      const bool valid = e < n;
+      key[j] = valid ? kbuf[cur][e] : 0xFFFFFFFFu;
+      const uint32_t d = (key[j] >> shift) & (TS_RADIX - 1);
+      unsigned long long mask = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        mask &= bit ? bal : ~bal;
+      }
+      const uint32_t before = (uint32_t) __popcll(mask & lt);
+      const uint32_t old = cnt[w][d];
+      if (valid && before == 0) cnt[w][d] = old + (uint32_t) __popcll(mask);
+      loc[j] = old + before;
+    }
+    __syncthreads();
+    // digit totals -> per-wave running bases, then an exclusive scan of the 256 totals
+    uint32_t total = 0;
+    if (tid < TS_RADIX) {
+#pragma unroll
+      for (int i = 0; i < TS_WAVES; ++i) {
+        const uint32_t c = cnt[i][tid];
+        cnt[i][tid] = total;
+        total += c;
+      }
+    }
+    uint32_t inc = total;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t x = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += x;
+    }
+    if (tid < TS_RADIX && lane == 63) wsum[w] = inc;
+    __syncthreads();
+    if (tid < TS_RADIX) {
+      uint32_t wb = 0;
+      for (int i = 0; i < w; ++i) wb += wsum[i];
+      dbase[tid] = wb + inc - total;
+    }
+    __syncthreads();
+    uint32_t val[TS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < TS_ITEMS; ++j) {
+      const int e = wbase + j * MI_WAVE + lane;
+      val[j] = e < n ? vbuf[cur][e] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < TS_ITEMS; ++j) {
+      const int e = wbase + j * MI_WAVE + lane;
+      if (e < n) {
+        const uint32_t d = (key[j] >> shift) & (TS_RADIX - 1);
+        const uint32_t pos = dbase[d] + cnt[w][d] + loc[j];
+        kbuf[cur ^ 1][pos] = key[j];
+        vbuf[cur ^ 1][pos] = val[j];
+      }
+    }
+    cur ^= 1;
+    __syncthreads();  // the scatter is complete (and cnt / dbase free) before the next pass
+  }
+  const size_t out = (size_t) t * n;
+#pragma unroll
+  for (int k = 0; k < TS_ITEMS; ++k) {
+    const int e = k * TS_THREADS + tid;
+    if (e < n) {
+      const uint32_t lk = kbuf[cur][e];
+      sorted_rows[out + e] = lk < rows ? (uint32_t) (base_row + lk) : sentinel;
+      perm[out + e] = vbuf[cur][e];
+    }
+  }
+}
+
 int bit_width_u64(uint64_t v) {
   int b = 0;
   while (v) { ++b; v >>= 1; }
@@ -343,7 +528,7 @@ extern "C" size_t mi_embag_bwd_workspace_bytes(int64_t n_entries) { return sort_
 
 extern "C" int mi_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int key_bits, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-  MI_REQUIRE(n >= 0 && n < ((int64_t) 1 << 31) - TILE, "mi_sort_pairs_u32: n out of range");
+  MI_REQUIRE(n >= 0 && n < ((int64_t) 1 << 31) - 4096, "mi_sort_pairs_u32: n out of range");
   MI_REQUIRE(key_bits >= 0 && key_bits <= 32, "mi_sort_pairs_u32: key_bits must be 0..32");
   if (n <= 1) return MI_OK;
   MI_REQUIRE(keys && vals && workspace, "mi_sort_pairs_u32: null pointer");
@@ -359,11 +544,13 @@ extern "C" int mi_embag_bwd_prepare(const int64_t* table_offsets, int T, int64_t
                                     int64_t n_entries, uint32_t* sorted_rows, int32_t* perm,
                                     uint32_t* unique_rows, int32_t* seg_offsets, int32_t* counts, void* workspace,
                                     size_t workspace_bytes, void* stream) {
-  MI_REQUIRE(table_offsets && indices && sorted_rows && perm && unique_rows && seg_offsets && counts,
-             "mi_embag_bwd_prepare: null pointer");
+  MI_REQUIRE(table_offsets && indices && sorted_rows && perm, "mi_embag_bwd_prepare: null pointer");
+  const bool want_runs = unique_rows && seg_offsets && counts;
+  MI_REQUIRE(want_runs || (!unique_rows && !seg_offsets && !counts),
+             "mi_embag_bwd_prepare: unique_rows, seg_offsets and counts must be all set or all NULL");
   MI_REQUIRE(T >= 1 && n_bags >= 0 && n_bags % T == 0, "mi_embag_bwd_prepare: n_bags must be a multiple of T");
   MI_REQUIRE(idx_bits == 32 || idx_bits == 64, "mi_embag_bwd_prepare: idx_bits must be 32 or 64");
-  MI_REQUIRE(n_entries >= 0 && n_entries < ((int64_t) 1 << 31) - TILE, "mi_embag_bwd_prepare: n_entries out of range");
+  MI_REQUIRE(n_entries >= 0 && n_entries < ((int64_t) 1 << 31) - 4096, "mi_embag_bwd_prepare: n_entries out of range");
   MI_REQUIRE(offsets || (bag_len >= 1 && n_entries == n_bags * bag_len),
              "mi_embag_bwd_prepare: n_entries must equal n_bags*bag_len for fixed-width bags");
   if (total_rows < 1 || total_rows >= (int64_t) 0xFFFFFFFFll) {
@@ -372,8 +559,10 @@ extern "C" int mi_embag_bwd_prepare(const int64_t* table_offsets, int T, int64_t
   }
   hipStream_t s = (hipStream_t) stream;
   if (n_entries == 0) {
-    MI_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), s));
-    MI_HIP(hipMemsetAsync(seg_offsets, 0, sizeof(int32_t), s));
+    if (want_runs) {
+      MI_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), s));
+      MI_HIP(hipMemsetAsync(seg_offsets, 0, sizeof(int32_t), s));
+    }
     return MI_OK;
   }
   MI_REQUIRE(workspace, "mi_embag_bwd_prepare: null workspace");
@@ -384,18 +573,38 @@ extern "C" int mi_embag_bwd_prepare(const int64_t* table_offsets, int T, int64_t
   const int n = (int) n_entries;
   const SortWs ws = carve(workspace, n_entries);
   const uint32_t sentinel = (uint32_t) total_rows;  // greater than every valid row
+  if (!want_runs && !offsets && n / T <= TS_MAX) {
+    // fixed-width bags, few enough entries per table: one launch, every table sorted in LDS.
+    // (Only without run arrays: padding entries then end each table's block, not the array.)
+    const int per_table = n / T;
+    if (idx_bits == 32)
+      hipLaunchKernelGGL(table_sort_kernel<int32_t>, dim3(T), dim3(TS_THREADS), 0, s, table_offsets, T, indices,
+                         bag_len, per_table, sentinel, sorted_rows, reinterpret_cast<uint32_t*>(perm));
+    else
+      hipLaunchKernelGGL(table_sort_kernel<int64_t>, dim3(T), dim3(TS_THREADS), 0, s, table_offsets, T, indices,
+                         bag_len, per_table, sentinel, sorted_rows, reinterpret_cast<uint32_t*>(perm));
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+  }
   const unsigned kgrid = (unsigned) mi_cdiv(n, 256);
   uint32_t* vals = reinterpret_cast<uint32_t*>(perm);
+  const int key_bits = bit_width_u64((uint64_t) total_rows);
+  int passes, rb;
+  pass_plan(key_bits, &passes, &rb);
+  const bool odd = (passes & 1) != 0;   // odd pass count: start in the alternate buffers, end in place
+  uint32_t* k0 = odd ? ws.keys_alt : sorted_rows;
+  uint32_t* v0 = odd ? ws.vals_alt : vals;
   if (idx_bits == 32)
     hipLaunchKernelGGL(keygen_kernel<int32_t>, dim3(kgrid), dim3(256), 0, s, table_offsets, T, indices, offsets,
-                       bag_len, (int) n_bags, n, sentinel, sorted_rows, vals);
+                       bag_len, (int) n_bags, n, sentinel, k0, v0);
   else
     hipLaunchKernelGGL(keygen_kernel<int64_t>, dim3(kgrid), dim3(256), 0, s, table_offsets, T, indices, offsets,
-                       bag_len, (int) n_bags, n, sentinel, sorted_rows, vals);
+                       bag_len, (int) n_bags, n, sentinel, k0, v0);
   MI_LAUNCH_CHECK();
-  const int rc = radix_sort(sorted_rows, vals, n, bit_width_u64((uint64_t) total_rows), ws, s);
+  const int rc = radix_sort(sorted_rows, vals, n, key_bits, ws, s, odd);
   if (rc != MI_OK) return rc;
-  const int nblk = (int) mi_cdiv(n, SEG_TILE);  // == ws.tiles (same tile size)
+  if (!want_runs) return MI_OK;
+  const int nblk = (int) mi_cdiv(n, SEG_TILE);  // <= ws.tiles
   hipLaunchKernelGGL(seg_count_kernel, dim3(nblk), dim3(256), 0, s, sorted_rows, n, sentinel, ws.seg_blocks, nblk);
   hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws.seg_blocks, nblk, counts, seg_offsets);
   hipLaunchKernelGGL(seg_write_kernel, dim3(nblk), dim3(256), 0, s, sorted_rows, n, sentinel, ws.seg_blocks,

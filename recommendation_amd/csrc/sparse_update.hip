@@ -7,28 +7,39 @@
 // reproduce exactly that, the other updaters touch only the rows present in the batch.
 //
 // Work split: a run (entries of one distinct row, contiguous after the sort) is served by
-// dim/VEC adjacent lanes, each owning VEC columns.  Runs longer than LONG_RUN are queued
-// to `long_list` and handled by a second launch in which a whole workgroup strides over
-// the run and combines its partial sums through LDS in a fixed tree, so hot rows (a
-// table with three rows gets a third of the batch each) do not serialise on four lanes.
+// dim/VEC adjacent lanes, each owning VEC columns.  A serial loop over a run is a chain of
+// dependent loads (permutation entry -> gradient source), so a lane group sums only runs of up
+// to GROUP_MAX entries itself (all loads of a run issued together); a longer run of up to
+// WAVE_MAX entries is summed by the whole wave that met it,
+// and longer ones are queued to `long_list` for a second launch in which a workgroup strides
+// over the run.  Partial sums are combined in fixed trees, so hot rows (a table with three
+// rows gets a third of the batch each) neither serialise on four lanes nor change bits from
+// run to run.
+//
+// Runs come either from the compacted arrays of mi_embag_bwd_prepare (unique_rows /
+// seg_offsets) or, when the plan carries none, straight from sorted_rows: one wave per 64
+// sorted entries finds the heads of the runs that start there with a ballot.  The second form
+// saves the three run-detection launches per step.
 #include "common.h"
 
 namespace {
 
-constexpr int LONG_RUN = 96;
+constexpr int WAVE_MAX = 256;   // one wave sums runs up to this; longer runs are queued for a workgroup
 constexpr int UBLOCK = 256;
-constexpr int LONG_GRID = 1024;
+constexpr int LONG_GRID = 512;
 
 struct PlanDev {
+  const uint32_t* sorted_rows;
   const uint32_t* unique_rows;
   const int32_t* perm;
   const int32_t* seg_offsets;
   const int32_t* counts;
-  int32_t* long_list;
+  int32_t* long_list;  // [0] count, [1] finished-workgroup ticket, [2..] queued runs
   const int64_t* offsets;
   const void* indices;
   const int64_t* toffs;
-  int n_bags, bag_len, T, pool_mode, idx_bits;
+  uint32_t sentinel;
+  int n, n_bags, bag_len, T, pool_mode, idx_bits;
 
   __device__ __forceinline__ int bag_of(int p) const {
     if (!offsets) return p / bag_len;
@@ -118,166 +129,418 @@ __device__ __forceinline__ float group_sum(float v, int lanes) {
 
 struct OptArgs {
   float lr, beta1, beta2, eps;
+  const float* lr_dev;  // when set, the step size is read from device memory (a schedule kept on the device)
+  __device__ __forceinline__ float step() const { return lr_dev ? *lr_dev : lr; }
 };
 
+// What an optimizer step reads from the row, loaded EARLY (as soon as the row is known) so
+// that these loads fly together with the gradient gather instead of after it.
 template <int OPT, int VEC>
-__device__ __forceinline__ void opt_row(float* w, float* s0, float* s1, int64_t row, int dim, int c, int lanes,
-                                        const float* g, const OptArgs& a) {
-  const int64_t off = row * dim + c * VEC;
-  float wv[VEC];
-  ldv<VEC>(w + off, wv);
+struct OptRegs {
+  float w[VEC], s0[VEC], s1[VEC];
+};
+
+// w, s0, s1 point at THIS row's data: w[dim]; s0 = Adagrad accumulator (1 float) or Adam m[dim];
+// s1 = Adam v[dim].
+template <int OPT, int VEC>
+__device__ __forceinline__ void opt_load(const float* w, const float* s0, const float* s1, int c,
+                                         OptRegs<OPT, VEC>& r) {
+  ldv<VEC>(w + c * VEC, r.w);
+  if constexpr (OPT == MI_OPT_ADAGRAD_ROWWISE) {
+    r.s0[0] = s0[0];
+  } else if constexpr (OPT == MI_OPT_ADAM_TF) {
+    ldv<VEC>(s0 + c * VEC, r.s0);
+    ldv<VEC>(s1 + c * VEC, r.s1);
+  }
+}
+
+template <int OPT, int VEC>
+__device__ __forceinline__ void opt_finish(float* w, float* s0, float* s1, int dim, int c, int lanes, const float* g,
+                                           const OptArgs& a, OptRegs<OPT, VEC>& r) {
+  const int off = c * VEC;
   if constexpr (OPT == MI_OPT_SGD) {
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) wv[k] -= a.lr * g[k];
+    for (int k = 0; k < VEC; ++k) r.w[k] -= a.step() * g[k];
   } else if constexpr (OPT == MI_OPT_ADAGRAD_ROWWISE) {
     float ss = 0.f;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) ss += g[k] * g[k];
     ss = group_sum(ss, lanes);
-    const float st = s0[row] + ss / (float) dim;
-    const float inv = a.lr / (sqrtf(st) + a.eps);
+    const float st = r.s0[0] + ss / (float) dim;
+    const float inv = a.step() / (sqrtf(st) + a.eps);
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) wv[k] -= inv * g[k];
-    if (c == 0) s0[row] = st;
+    for (int k = 0; k < VEC; ++k) r.w[k] -= inv * g[k];
+    if (c == 0) s0[0] = st;
   } else {  // MI_OPT_ADAM_TF
-    float mv[VEC], vv[VEC];
-    ldv<VEC>(s0 + off, mv);
-    ldv<VEC>(s1 + off, vv);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       // the three statements of TensorFlow's ApplyAdam kernel, (1 - beta) formed in fp32 as there
-      mv[k] += (g[k] - mv[k]) * (1.0f - a.beta1);
-      vv[k] += (g[k] * g[k] - vv[k]) * (1.0f - a.beta2);
-      wv[k] -= (mv[k] * a.lr) / (sqrtf(vv[k]) + a.eps);
+      r.s0[k] += (g[k] - r.s0[k]) * (1.0f - a.beta1);
+      r.s1[k] += (g[k] * g[k] - r.s1[k]) * (1.0f - a.beta2);
+      r.w[k] -= (r.s0[k] * a.step()) / (sqrtf(r.s1[k]) + a.eps);
     }
-    stv<VEC>(s0 + off, mv);
-    stv<VEC>(s1 + off, vv);
+    stv<VEC>(s0 + off, r.s0);
+    stv<VEC>(s1 + off, r.s1);
   }
-  stv<VEC>(w + off, wv);
+  stv<VEC>(w + off, r.w);
 }
 
-// ---- row updaters -------------------------------------------------------------------------
+// ---- row updaters: load(row) early, finish(row, summed gradient) late -----------------------
 template <int OPT>
 struct BagUpd {
   float* w; float* s0; float* s1; int dim; OptArgs a;
+  template <int VEC> using Regs = OptRegs<OPT, VEC>;
+  __device__ __forceinline__ float* p0(int64_t row) const {
+    return s0 ? (OPT == MI_OPT_ADAGRAD_ROWWISE ? s0 + row : s0 + row * dim) : nullptr;
+  }
+  __device__ __forceinline__ float* p1(int64_t row) const { return s1 ? s1 + row * dim : nullptr; }
   template <int VEC>
-  __device__ __forceinline__ void apply(int64_t row, int c, int lanes, const float* g, float) const {
-    opt_row<OPT, VEC>(w, s0, s1, row, dim, c, lanes, g, a);
+  __device__ __forceinline__ void load(int64_t row, int c, Regs<VEC>& r) const {
+    opt_load<OPT, VEC>(w + row * dim, p0(row), p1(row), c, r);
+  }
+  template <int VEC>
+  __device__ __forceinline__ void finish(int64_t row, int c, int lanes, Regs<VEC>& r, const float* g, float) const {
+    opt_finish<OPT, VEC>(w + row * dim, p0(row), p1(row), dim, c, lanes, g, a, r);
   }
 };
 
+struct NoRegs {};
 struct DenseGradUpd {
   float* dW; int dim;
+  template <int VEC> using Regs = NoRegs;
   template <int VEC>
-  __device__ __forceinline__ void apply(int64_t row, int c, int, const float* g, float) const {
+  __device__ __forceinline__ void load(int64_t, int, NoRegs&) const {}
+  template <int VEC>
+  __device__ __forceinline__ void finish(int64_t row, int c, int, NoRegs&, const float* g, float) const {
     stv<VEC>(dW + row * dim + c * VEC, g);
   }
 };
 
+// FM row record: V, w1 and their optimizer state side by side (see mi_fm_table)
+template <int OPT, int VEC>
+struct FmRegs {
+  OptRegs<OPT, VEC> v;
+  OptRegs<OPT, 1> w;
+};
 template <int OPT>
 struct FmUpd {
-  float* V; float* w1; float* st0; float* st1; float* st2; float* st3; int dim; OptArgs a;
+  mi_fm_table t; OptArgs a;
+  template <int VEC> using Regs = FmRegs<OPT, VEC>;
   template <int VEC>
-  __device__ __forceinline__ void apply(int64_t row, int c, int lanes, const float* acc, float gsum) const {
-    float vr[VEC], gr[VEC];
-    ldv<VEC>(V + row * dim + c * VEC, vr);
+  __device__ __forceinline__ void load(int64_t row, int c, Regs<VEC>& r) const {
+    const float* rec = t.rec + row * t.stride;
+    opt_load<OPT, VEC>(rec, rec + t.off_vs0, rec + t.off_vs1, c, r.v);
+    if (c == 0) opt_load<OPT, 1>(rec + t.off_w1, rec + t.off_ws0, rec + t.off_ws1, 0, r.w);
+  }
+  template <int VEC>
+  __device__ __forceinline__ void finish(int64_t row, int c, int lanes, Regs<VEC>& r, const float* acc,
+                                         float gsum) const {
+    float* rec = t.rec + row * t.stride;
+    float gr[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) gr[k] = acc[k] - vr[k] * gsum;
-    if constexpr (OPT == MI_OPT_ADAGRAD_ROWWISE) {
-      opt_row<OPT, VEC>(V, st0, nullptr, row, dim, c, lanes, gr, a);
-      if (c == 0) opt_row<OPT, 1>(w1, st1, nullptr, row, 1, 0, 1, &gsum, a);
-    } else {
-      opt_row<OPT, VEC>(V, st0, st1, row, dim, c, lanes, gr, a);
-      if (c == 0) opt_row<OPT, 1>(w1, st2, st3, row, 1, 0, 1, &gsum, a);
-    }
+    for (int k = 0; k < VEC; ++k) gr[k] = acc[k] - r.v.w[k] * gsum;
+    opt_finish<OPT, VEC>(rec, rec + t.off_vs0, rec + t.off_vs1, t.dim, c, lanes, gr, a, r.v);
+    if (c == 0) opt_finish<OPT, 1>(rec + t.off_w1, rec + t.off_ws0, rec + t.off_ws1, 1, 0, 1, &gsum, a, r.w);
   }
 };
 
 // ---- kernels ------------------------------------------------------------------------------
-template <int VEC, class Src, class Upd>
-__global__ __launch_bounds__(UBLOCK) void seg_short_kernel(PlanDev pl, Src src, Upd upd, int lanes, int gpb) {
-  const int sub = threadIdx.x / lanes;
-  const int c = threadIdx.x - sub * lanes;
-  if (sub >= gpb) return;
-  const int u = blockIdx.x * gpb + sub;
-  if (u >= pl.counts[0]) return;
-  const int beg = pl.seg_offsets[u], end = pl.seg_offsets[u + 1];
-  if (end - beg > LONG_RUN) {
-    if (c == 0) {
-      const int slot = atomicAdd(&pl.long_list[0], 1);
-      pl.long_list[1 + slot] = u;
-    }
-    return;
+// Sum of the gradient sources of entries beg, beg+step, ... < end (fixed order).  Rounds of
+// eight: the permutation entries of round r+1 are requested before the sources of round r are
+// consumed, so a round costs one dependent memory round trip, not two.
+template <int VEC, class Src>
+__device__ __forceinline__ void sum_run(const PlanDev& pl, const Src& src, int c, int beg, int end, int step,
+                                        float* acc, float& sc) {
+  constexpr int UR = 8;
+  if (beg >= end) return;
+  int p[UR];
+  bool in[UR];
+#pragma unroll
+  for (int i = 0; i < UR; ++i) {
+    in[i] = beg + i * step < end;
+    p[i] = pl.perm[in[i] ? beg + i * step : beg];
   }
+  for (int e = beg; e < end; e += UR * step) {
+    float v[UR][VEC], s[UR];
+#pragma unroll
+    for (int i = 0; i < UR; ++i) src.template load<VEC>(pl, p[i], c, v[i], s[i]);
+    bool cur[UR];
+#pragma unroll
+    for (int i = 0; i < UR; ++i) cur[i] = in[i];
+    const int nx = e + UR * step;
+    if (nx < end) {
+#pragma unroll
+      for (int i = 0; i < UR; ++i) {
+        in[i] = nx + i * step < end;
+        p[i] = pl.perm[in[i] ? nx + i * step : nx];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < UR; ++i) {
+      if (cur[i]) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += v[i][k];
+        sc += s[i];
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void queue_long(const PlanDev& pl, int token) {
+  const int slot = atomicAdd(&pl.long_list[0], 1);
+  pl.long_list[2 + slot] = token;
+}
+
+// End of the run that starts at `beg` (first index whose row is greater; rows ascend and the
+// sentinel is the largest), found by one wave: first a 64 x 16 window (runs up to 1024 take two
+// dependent loads), then a 64-way search of whatever is left (3 more for 2^18 entries).
+__device__ __forceinline__ int run_end_wave(const uint32_t* keys, int n, int beg, uint32_t row) {
+  const int lane = threadIdx.x & 63;
+  int lo = beg + 1, hi = n;  // answer in [lo, hi]
+  bool first = true;
+  while (lo < hi) {
+    const int span = hi - lo;
+    int step = (span + 63) / 64;
+    if (first && step > 16) step = 16;  // first look only 1024 entries ahead
+    first = false;
+    const int idx = lo + lane * step;
+    const bool gt = idx >= hi || keys[idx] > row;
+    const unsigned long long m = __ballot(gt);   // monotone: 0..0 1..1
+    const int f = m ? __ffsll((long long) m) - 1 : 64;
+    const int new_hi = f < 64 ? min(hi, lo + f * step) : hi;
+    const int new_lo = f > 0 ? lo + (f - 1) * step + 1 : lo;
+    lo = new_lo;
+    hi = new_hi;
+  }
+  return lo;
+}
+
+// One wave sums the run [beg, end) of `row`: its 64/lanes lane groups stride over the entries,
+// then a fixed shuffle tree combines them and group 0 applies the update.  Every lane of the
+// wave must call this together.  Needs lanes to be a power of two <= 64.
+template <int VEC, class Src, class Upd>
+__device__ __forceinline__ void wave_run(const PlanDev& pl, const Src& src, const Upd& upd, int lanes, int beg,
+                                         int end, uint32_t row) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / lanes, c = lane - sub * lanes, wgroups = 64 / lanes;
+  typename Upd::template Regs<VEC> regs;
+  if (sub == 0) upd.template load<VEC>((int64_t) row, c, regs);
   float acc[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
   float sc = 0.f;
-  int e = beg;
-  for (; e + 4 <= end; e += 4) {
-    int p[4];
+  sum_run<VEC>(pl, src, c, beg + sub, end, wgroups, acc, sc);
+  for (int o = lanes; o < 64; o <<= 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) p[i] = pl.perm[e + i];
-    float v[4][VEC], s[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) src.template load<VEC>(pl, p[i], c, v[i], s[i]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[k] += v[i][k];
-      sc += s[i];
-    }
+    for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
+    sc += __shfl_xor(sc, o, 64);
   }
-  for (; e < end; ++e) {
-    float v[VEC], s;
-    src.template load<VEC>(pl, pl.perm[e], c, v, s);
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] += v[k];
-    sc += s;
-  }
-  upd.template apply<VEC>((int64_t) pl.unique_rows[u], c, lanes, acc, sc);
+  if (sub == 0) upd.template finish<VEC>((int64_t) row, c, lanes, regs, acc, sc);
 }
 
+// A lane group sums a run of up to 4 / up to 16 entries: all permutation entries in one round
+// trip, all gradient sources in the next, added in entry order.
+template <int VEC, class Src>
+__device__ __forceinline__ void group_sum4(const PlanDev& pl, const Src& src, int c, int beg, int len, float* acc,
+                                           float& sc) {
+  int p[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p[q] = pl.perm[q < len ? beg + q : beg];
+  float v[4][VEC], s[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) src.template load<VEC>(pl, p[q], c, v[q], s[q]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q < len) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += v[q][k];
+      sc += s[q];
+    }
+  }
+}
+
+template <int VEC, class Src>
+__device__ __forceinline__ void group_sum16(const PlanDev& pl, const Src& src, int c, int beg, int len, float* acc,
+                                            float& sc) {
+  int p[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) p[q] = pl.perm[q < len ? beg + q : beg];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float v[8][VEC], s[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) src.template load<VEC>(pl, p[h * 8 + q], c, v[q], s[q]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (h * 8 + q < len) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += v[q][k];
+        sc += s[q];
+      }
+    }
+  }
+}
+
+// A lane group owns the run [beg, beg+len) of `row`, len <= 16: sum and apply.
 template <int VEC, class Src, class Upd>
-__global__ __launch_bounds__(UBLOCK) void seg_long_kernel(PlanDev pl, Src src, Upd upd, int lanes, int groups) {
-  __shared__ float red[UBLOCK * VEC];
-  __shared__ float reds[UBLOCK];
+__device__ __forceinline__ void group_run(const PlanDev& pl, const Src& src, const Upd& upd, int lanes, int c,
+                                          int beg, int len, uint32_t row) {
+  typename Upd::template Regs<VEC> regs;
+  upd.template load<VEC>((int64_t) row, c, regs);
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+  float sc = 0.f;
+  if (len <= 4) group_sum4<VEC>(pl, src, c, beg, len, acc, sc);
+  else group_sum16<VEC>(pl, src, c, beg, len, acc, sc);
+  upd.template finish<VEC>((int64_t) row, c, lanes, regs, acc, sc);
+}
+
+constexpr int GROUP_MAX = 16;  // a lane group sums runs up to this itself
+
+// The runs some lane groups of a wave could not take (more than GROUP_MAX entries, or end not
+// known yet: end < 0) are summed by the whole wave, one after the other; only runs beyond
+// WAVE_MAX go to the queue.  Every lane of the wave must call this together.
+template <int VEC, class Src, class Upd>
+__device__ __forceinline__ void wave_pending(const PlanDev& pl, const Src& src, const Upd& upd, int lanes,
+                                             bool pending, int beg, int end, uint32_t row, int token) {
+  unsigned long long todo = __ballot(pending);
+  while (todo) {  // uniform over the wave
+    const int from = __ffsll((long long) todo) - 1;
+    todo &= todo - 1;
+    const int rb = __shfl(beg, from, 64);
+    int re = __shfl(end, from, 64);
+    const uint32_t rr = (uint32_t) __shfl((int) row, from, 64);
+    const int tk = __shfl(token, from, 64);
+    if (re < 0) re = run_end_wave(pl.sorted_rows, pl.n, rb, rr);
+    if (re - rb > WAVE_MAX) {
+      if ((threadIdx.x & 63) == 0) queue_long(pl, tk);
+      continue;
+    }
+    wave_run<VEC>(pl, src, upd, lanes, rb, re, rr);
+  }
+}
+
+// Runs from the compacted arrays of the plan: one lane group per distinct row.
+template <int VEC, class Src, class Upd>
+__global__ __launch_bounds__(UBLOCK) void seg_runs_kernel(PlanDev pl, Src src, Upd upd, int lanes, int gpb,
+                                                         int wave_ok) {
   const int sub = threadIdx.x / lanes;
   const int c = threadIdx.x - sub * lanes;
+  const int item = blockIdx.x * gpb + sub;
+  int beg = 0, end = 0;
+  uint32_t row = 0;
+  bool pending = false;
+  if (sub < gpb && item < pl.counts[0]) {
+    beg = pl.seg_offsets[item];
+    end = pl.seg_offsets[item + 1];
+    row = pl.unique_rows[item];
+    if (end - beg <= GROUP_MAX) group_run<VEC>(pl, src, upd, lanes, c, beg, end - beg, row);
+    else pending = (c == 0);
+  }
+  if (!wave_ok) {  // lane groups straddle waves: longer runs all go to the queue
+    if (pending) queue_long(pl, item);
+    return;
+  }
+  wave_pending<VEC>(pl, src, upd, lanes, pending, beg, end, row, item);
+}
+
+// position of the k-th (0-based) set bit of m; k < popcount(m)
+__device__ __forceinline__ int kth_set_bit(unsigned long long m, int k) {
+  int pos = 0;
+#pragma unroll
+  for (int b = 32; b > 0; b >>= 1) {
+    const unsigned long long prefix = m & ((1ull << (pos + b)) - 1ull);  // bits [0, pos+b), pos+b <= 63
+    if (__popcll(prefix) <= k) pos += b;
+  }
+  return pos;
+}
+
+// Runs straight from sorted_rows (no run arrays in the plan): one WAVE per 64 consecutive sorted
+// entries.  Lane l holds entry l's row; a ballot of "row differs from the predecessor's" gives
+// the heads of the runs that start in this wave and, from the distance to the next head, their
+// lengths - one coalesced load instead of per-run probing.  The wave's 64/lanes lane groups
+// then take the heads 64/lanes at a time.  A run that continues past the wave's last entry, or
+// is longer than GROUP_MAX, is left to the whole wave (wave_pending).
+template <int VEC, class Src, class Upd>
+__global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src, Upd upd, int lanes) {
+  const int lane = threadIdx.x & 63;
+  const int base = (blockIdx.x * (UBLOCK / 64) + (threadIdx.x >> 6)) * 64;
+  if (base >= pl.n) return;  // uniform over the wave
+  const uint32_t* keys = pl.sorted_rows;
+  const uint32_t sentinel = pl.sentinel;
+  const int i = base + lane;
+  const uint32_t key = i < pl.n ? keys[i] : sentinel;
+  uint32_t edge = sentinel;  // lane 0: the row before the wave's first; lane 63: the row after its last
+  if (lane == 0 && base > 0) edge = keys[base - 1];
+  if (lane == 63 && base + 64 < pl.n) edge = keys[base + 64];
+  uint32_t prev = (uint32_t) __shfl_up((int) key, 1, 64);
+  const uint32_t before = (uint32_t) __shfl((int) edge, 0, 64);
+  const uint32_t after_wave = (uint32_t) __shfl((int) edge, 63, 64);
+  if (lane == 0) prev = base > 0 ? before : ~key;
+  // Every change of row starts a run, padding (sentinel) runs included - those are skipped below.
+  // (After a per-table sort the sentinels close each table's block instead of the whole array.)
+  const bool head = key != prev;
+  const unsigned long long hm = __ballot(head);
+  const int nheads = __popcll(hm);
+  const int G = 64 / lanes, g = lane / lanes, c = lane - g * lanes;
+  for (int r = 0; r * G < nheads; ++r) {  // uniform over the wave
+    const int k = r * G + g;
+    const int pos = k < nheads ? kth_set_bit(hm, k) : 0;
+    const unsigned long long later = (pos < 63) ? (hm & ~((2ull << pos) - 1ull)) : 0ull;  // heads after pos
+    const int endpos = later ? __ffsll((long long) later) - 1 : 64;
+    const uint32_t row = (uint32_t) __shfl((int) key, pos, 64);
+    const bool have = k < nheads && row != sentinel;
+    const bool open = have && !later && base + 64 < pl.n && after_wave == row;  // continues in the next wave
+    const int len = endpos - pos;
+    bool pending = false;
+    if (have) {
+      if (!open && len <= GROUP_MAX) group_run<VEC>(pl, src, upd, lanes, c, base + pos, len, row);
+      else pending = (c == 0);
+    }
+    wave_pending<VEC>(pl, src, upd, lanes, pending, base + pos, open ? -1 : base + endpos, row, base + pos);
+  }
+}
+
+// Queued runs (longer than WAVE_MAX, or longer than 4 when lane groups straddle waves): one
+// workgroup per run strides over the entries and combines partial sums through a fixed LDS
+// tree.  The order of additions depends only on the run's length: reproducible bit for bit.
+template <int VEC, class Src, class Upd>
+__global__ __launch_bounds__(UBLOCK) void seg_queue_kernel(PlanDev pl, Src src, Upd upd, int lanes, int groups) {
+  __shared__ float red[UBLOCK * VEC];
+  __shared__ float reds[UBLOCK];
+  __shared__ int sh_end;
+  const int sub = threadIdx.x / lanes, c = threadIdx.x - sub * lanes;
   const bool active = sub < groups;
-  const int n_long = pl.long_list[0];
+  const int n_q = pl.long_list[0];
   int top = 1;
   while (top < groups) top <<= 1;
-  for (int i = blockIdx.x; i < n_long; i += gridDim.x) {
-    const int u = pl.long_list[1 + i];
-    const int beg = pl.seg_offsets[u], end = pl.seg_offsets[u + 1];
+  for (int i = blockIdx.x; i < n_q; i += gridDim.x) {
+    const int token = pl.long_list[2 + i];
+    int beg, end;
+    uint32_t row;
+    if (pl.seg_offsets) {
+      beg = pl.seg_offsets[token];
+      end = pl.seg_offsets[token + 1];
+      row = pl.unique_rows[token];
+    } else {
+      beg = token;
+      row = pl.sorted_rows[token];
+      if (threadIdx.x < 64) {
+        const int e = run_end_wave(pl.sorted_rows, pl.n, beg, row);
+        if (threadIdx.x == 0) sh_end = e;
+      }
+      __syncthreads();
+      end = sh_end;
+    }
+    typename Upd::template Regs<VEC> regs;
+    if (sub == 0) upd.template load<VEC>((int64_t) row, c, regs);
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
     float sc = 0.f;
     if (active) {
-      int e = beg + sub;
-      for (; e + 3 * groups < end; e += 4 * groups) {
-        int p[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) p[q] = pl.perm[e + q * groups];
-        float v[4][VEC], s[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) src.template load<VEC>(pl, p[q], c, v[q], s[q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) acc[k] += v[q][k];
-          sc += s[q];
-        }
-      }
-      for (; e < end; e += groups) {
-        float v[VEC], s;
-        src.template load<VEC>(pl, pl.perm[e], c, v, s);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] += v[k];
-        sc += s;
-      }
+      sum_run<VEC>(pl, src, c, beg + sub, end, groups, acc, sc);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) red[(sub * lanes + c) * VEC + k] = acc[k];
       reds[sub * lanes + c] = sc;
@@ -295,9 +558,18 @@ __global__ __launch_bounds__(UBLOCK) void seg_long_kernel(PlanDev pl, Src src, U
       float g[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) g[k] = red[c * VEC + k];
-      upd.template apply<VEC>((int64_t) pl.unique_rows[u], c, lanes, g, reds[c]);
+      upd.template finish<VEC>((int64_t) row, c, lanes, regs, g, reds[c]);
     }
     __syncthreads();
+  }
+  // The workgroup that finishes last leaves the queue empty for the next call: every
+  // workgroup read the count before taking its ticket, so nobody still needs it.
+  if (threadIdx.x == 0) {
+    const int ticket = atomicAdd(&pl.long_list[1], 1);
+    if (ticket == (int) gridDim.x - 1) {
+      atomicExch(&pl.long_list[0], 0);
+      atomicExch(&pl.long_list[1], 0);
+    }
   }
 }
 
@@ -316,19 +588,15 @@ __global__ __launch_bounds__(UBLOCK) void adam_dense_kernel(PlanDev pl, BagGradS
     const int mid = (lo + hi) >> 1;
     if ((int64_t) pl.unique_rows[mid] < row) lo = mid + 1; else hi = mid;
   }
+  OptRegs<MI_OPT_ADAM_TF, VEC> regs;
+  upd.template load<VEC>(row, c, regs);
   float acc[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-  if (lo < n_unique && (int64_t) pl.unique_rows[lo] == row) {
-    const int beg = pl.seg_offsets[lo], end = pl.seg_offsets[lo + 1];
-    for (int e = beg; e < end; ++e) {
-      float v[VEC], s;
-      src.template load<VEC>(pl, pl.perm[e], c, v, s);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[k] += v[k];
-    }
-  }
-  upd.template apply<VEC>(row, c, lanes, acc, 0.f);
+  float sc = 0.f;
+  if (lo < n_unique && (int64_t) pl.unique_rows[lo] == row)
+    sum_run<VEC>(pl, src, c, pl.seg_offsets[lo], pl.seg_offsets[lo + 1], 1, acc, sc);
+  upd.template finish<VEC>(row, c, lanes, regs, acc, 0.f);
 }
 
 // ---- host side --------------------------------------------------------------------------
@@ -347,18 +615,23 @@ int geometry(int dim, bool aligned16, Geometry* g) {
   return MI_OK;
 }
 
-int check_plan(const mi_bwd_plan* plan, PlanDev* pl, const char* who) {
+int check_plan(const mi_bwd_plan* plan, PlanDev* pl, bool need_runs, const char* who) {
   MI_REQUIRE(plan, "%s: null plan", who);
-  MI_REQUIRE(plan->sorted_rows && plan->perm && plan->unique_rows && plan->seg_offsets && plan->counts &&
-                 plan->long_list,
-             "%s: plan has a null pointer", who);
+  MI_REQUIRE(plan->sorted_rows && plan->perm && plan->long_list, "%s: plan has a null pointer", who);
+  const bool has_runs = plan->unique_rows && plan->seg_offsets && plan->counts;
+  MI_REQUIRE(has_runs || (!plan->unique_rows && !plan->seg_offsets && !plan->counts),
+             "%s: unique_rows, seg_offsets and counts must be all set or all NULL", who);
+  MI_REQUIRE(has_runs || !need_runs, "%s: this entry point needs the compacted runs in the plan", who);
   MI_REQUIRE(plan->T >= 1 && plan->n_entries >= 0 && plan->n_entries < ((int64_t) 1 << 31),
              "%s: plan T / n_entries out of range", who);
+  MI_REQUIRE(plan->total_rows >= 1 && plan->total_rows < (int64_t) 0xFFFFFFFFll, "%s: plan total_rows out of range",
+             who);
   MI_REQUIRE(plan->offsets || plan->bag_len >= 1, "%s: plan needs offsets or bag_len >= 1", who);
   MI_REQUIRE(plan->pool_mode == MI_POOL_SUM ||
                  (plan->pool_mode == MI_POOL_MEAN && plan->indices && plan->table_offsets &&
                   (plan->idx_bits == 32 || plan->idx_bits == 64)),
              "%s: mean pooling needs indices, idx_bits and table_offsets in the plan", who);
+  pl->sorted_rows = plan->sorted_rows;
   pl->unique_rows = plan->unique_rows;
   pl->perm = plan->perm;
   pl->seg_offsets = plan->seg_offsets;
@@ -367,6 +640,8 @@ int check_plan(const mi_bwd_plan* plan, PlanDev* pl, const char* who) {
   pl->offsets = plan->offsets;
   pl->indices = plan->indices;
   pl->toffs = plan->table_offsets;
+  pl->sentinel = (uint32_t) plan->total_rows;
+  pl->n = (int) plan->n_entries;
   pl->n_bags = (int) plan->n_bags;
   pl->bag_len = plan->bag_len;
   pl->T = plan->T;
@@ -379,17 +654,33 @@ template <class Src, class Upd>
 int run_segments(const mi_bwd_plan* plan, const PlanDev& pl, const Src& src, const Upd& upd, const Geometry& g,
                  hipStream_t s) {
   if (plan->n_entries == 0) return MI_OK;
-  MI_HIP(hipMemsetAsync(pl.long_list, 0, sizeof(int32_t), s));
-  const unsigned grid = (unsigned) mi_cdiv(plan->n_entries, g.gpb);
-  if (g.vec == 4) {
-    hipLaunchKernelGGL((seg_short_kernel<4, Src, Upd>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes, g.gpb);
-    hipLaunchKernelGGL((seg_long_kernel<4, Src, Upd>), dim3(LONG_GRID), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes,
-                       g.gpb);
+  const int wave_ok = (g.lanes <= 64 && (g.lanes & (g.lanes - 1)) == 0) ? 1 : 0;  // shuffle trees need 2^k lanes
+  if (pl.seg_offsets) {
+    const unsigned grid = (unsigned) mi_cdiv(plan->n_entries, g.gpb);
+    if (g.vec == 4)
+      hipLaunchKernelGGL((seg_runs_kernel<4, Src, Upd>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes, g.gpb,
+                         wave_ok);
+    else
+      hipLaunchKernelGGL((seg_runs_kernel<1, Src, Upd>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes, g.gpb,
+                         wave_ok);
   } else {
-    hipLaunchKernelGGL((seg_short_kernel<1, Src, Upd>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes, g.gpb);
-    hipLaunchKernelGGL((seg_long_kernel<1, Src, Upd>), dim3(LONG_GRID), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes,
-                       g.gpb);
+    if (!wave_ok) {
+      mi_set_error("sparse update: a plan without run arrays needs dim/%d = %d lanes per row to be a power of two <= 64",
+                   g.vec, g.lanes);
+      return MI_ERR_UNSUPPORTED;
+    }
+    const unsigned grid = (unsigned) mi_cdiv(plan->n_entries, UBLOCK);
+    if (g.vec == 4)
+      hipLaunchKernelGGL((seg_sorted_kernel<4, Src, Upd>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes);
+    else
+      hipLaunchKernelGGL((seg_sorted_kernel<1, Src, Upd>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes);
   }
+  if (g.vec == 4)
+    hipLaunchKernelGGL((seg_queue_kernel<4, Src, Upd>), dim3(LONG_GRID), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes,
+                       g.gpb);
+  else
+    hipLaunchKernelGGL((seg_queue_kernel<1, Src, Upd>), dim3(LONG_GRID), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes,
+                       g.gpb);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -401,7 +692,7 @@ template <int OPT>
 int bag_apply(const mi_bwd_plan* plan, const float* grad_out, int64_t grad_ld, int dim, float* w, float* s0,
               float* s1, OptArgs a, void* stream, const char* who) {
   PlanDev pl;
-  int rc = check_plan(plan, &pl, who);
+  int rc = check_plan(plan, &pl, false, who);
   if (rc) return rc;
   MI_REQUIRE(grad_out && w, "%s: null pointer", who);
   MI_REQUIRE(dim >= 1 && grad_ld >= (int64_t) plan->T * dim, "%s: grad_ld %lld < T*dim", who, (long long) grad_ld);
@@ -423,7 +714,7 @@ int bag_apply(const mi_bwd_plan* plan, const float* grad_out, int64_t grad_ld, i
 extern "C" int mi_embag_bwd_dense_grad(const mi_bwd_plan* plan, const float* grad_out, int64_t grad_ld, int dim,
                                        int64_t total_rows, float* dW, void* stream) {
   PlanDev pl;
-  int rc = check_plan(plan, &pl, "mi_embag_bwd_dense_grad");
+  int rc = check_plan(plan, &pl, false, "mi_embag_bwd_dense_grad");
   if (rc) return rc;
   MI_REQUIRE(grad_out && dW, "mi_embag_bwd_dense_grad: null pointer");
   MI_REQUIRE(dim >= 1 && total_rows >= 1 && grad_ld >= (int64_t) plan->T * dim, "mi_embag_bwd_dense_grad: bad shape");
@@ -439,7 +730,7 @@ extern "C" int mi_embag_bwd_dense_grad(const mi_bwd_plan* plan, const float* gra
 
 extern "C" int mi_embag_bwd_apply_sgd(const mi_bwd_plan* plan, const float* grad_out, int64_t grad_ld, int dim,
                                       float* weights, float lr, void* stream) {
-  return bag_apply<MI_OPT_SGD>(plan, grad_out, grad_ld, dim, weights, nullptr, nullptr, OptArgs{lr, 0, 0, 0}, stream,
+  return bag_apply<MI_OPT_SGD>(plan, grad_out, grad_ld, dim, weights, nullptr, nullptr, OptArgs{lr, 0, 0, 0, nullptr}, stream,
                                "mi_embag_bwd_apply_sgd");
 }
 
@@ -448,14 +739,14 @@ extern "C" int mi_embag_bwd_apply_adagrad_rowwise(const mi_bwd_plan* plan, const
                                                   void* stream) {
   MI_REQUIRE(state, "mi_embag_bwd_apply_adagrad_rowwise: null state");
   return bag_apply<MI_OPT_ADAGRAD_ROWWISE>(plan, grad_out, grad_ld, dim, weights, state, nullptr,
-                                           OptArgs{lr, 0, 0, eps}, stream, "mi_embag_bwd_apply_adagrad_rowwise");
+                                           OptArgs{lr, 0, 0, eps, nullptr}, stream, "mi_embag_bwd_apply_adagrad_rowwise");
 }
 
 extern "C" int mi_embag_bwd_apply_adam_tf(const mi_bwd_plan* plan, const float* grad_out, int64_t grad_ld, int dim,
                                           float* weights, float* m, float* v, float lr_t, float beta1, float beta2,
                                           float eps, void* stream) {
   MI_REQUIRE(m && v, "mi_embag_bwd_apply_adam_tf: null state");
-  return bag_apply<MI_OPT_ADAM_TF>(plan, grad_out, grad_ld, dim, weights, m, v, OptArgs{lr_t, beta1, beta2, eps},
+  return bag_apply<MI_OPT_ADAM_TF>(plan, grad_out, grad_ld, dim, weights, m, v, OptArgs{lr_t, beta1, beta2, eps, nullptr},
                                    stream, "mi_embag_bwd_apply_adam_tf");
 }
 
@@ -464,7 +755,7 @@ extern "C" int mi_embag_bwd_apply_adam_dense_tf(const mi_bwd_plan* plan, const f
                                                 float lr_t, float beta1, float beta2, float eps, void* stream) {
   const char* who = "mi_embag_bwd_apply_adam_dense_tf";
   PlanDev pl;
-  int rc = check_plan(plan, &pl, who);
+  int rc = check_plan(plan, &pl, true, who);
   if (rc) return rc;
   MI_REQUIRE(grad_out && weights && m && v, "%s: null pointer", who);
   MI_REQUIRE(dim >= 1 && total_rows >= 1 && grad_ld >= (int64_t) plan->T * dim, "%s: bad shape", who);
@@ -472,7 +763,7 @@ extern "C" int mi_embag_bwd_apply_adam_dense_tf(const mi_bwd_plan* plan, const f
   rc = geometry(dim, al16(grad_out) && al16(weights) && al16(m) && al16(v) && grad_ld % 4 == 0, &g);
   if (rc) return rc;
   BagGradSrc src{grad_out, grad_ld, dim};
-  BagUpd<MI_OPT_ADAM_TF> upd{weights, m, v, dim, OptArgs{lr_t, beta1, beta2, eps}};
+  BagUpd<MI_OPT_ADAM_TF> upd{weights, m, v, dim, OptArgs{lr_t, beta1, beta2, eps, nullptr}};
   const unsigned grid = (unsigned) mi_cdiv(total_rows, g.gpb);
   hipStream_t s = (hipStream_t) stream;
   if (g.vec == 4)
@@ -483,39 +774,40 @@ extern "C" int mi_embag_bwd_apply_adam_dense_tf(const mi_bwd_plan* plan, const f
   return MI_OK;
 }
 
-extern "C" int mi_fm_bwd_apply(const mi_bwd_plan* plan, const float* g, const float* S, int dim, float* V, float* w1,
-                               int opt, float* st0, float* st1, float* st2, float* st3, float lr, float beta1,
-                               float beta2, float eps, void* stream) {
+extern "C" int mi_fm_bwd_apply(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* g, const float* S,
+                               int opt, float lr, const float* lr_dev, float beta1, float beta2, float eps,
+                               void* stream) {
   const char* who = "mi_fm_bwd_apply";
   PlanDev pl;
-  int rc = check_plan(plan, &pl, who);
+  int rc = check_plan(plan, &pl, false, who);
   if (rc) return rc;
-  MI_REQUIRE(g && S && V && w1, "%s: null pointer", who);
+  MI_REQUIRE(g && S, "%s: null pointer", who);
+  rc = mi_fm_check_table(tab, opt, who);
+  if (rc) return rc;
   MI_REQUIRE(!plan->offsets && plan->bag_len == 1 && plan->pool_mode == MI_POOL_SUM,
              "%s: FM takes one id per field (bag_len 1, sum)", who);
+  MI_REQUIRE(al16(S), "%s: S must be 16-byte aligned", who);
   Geometry geo;
-  rc = geometry(dim, al16(S) && al16(V) && (!st0 || al16(st0)) && (!st1 || al16(st1)), &geo);
+  rc = geometry(tab->dim, true, &geo);
   if (rc) return rc;
-  FmSrc src{g, S, dim};
-  OptArgs a{lr, beta1, beta2, eps};
+  FmSrc src{g, S, tab->dim};
+  OptArgs a{lr, beta1, beta2, eps, lr_dev};
   hipStream_t s = (hipStream_t) stream;
   switch (opt) {
     case MI_OPT_SGD: {
-      FmUpd<MI_OPT_SGD> upd{V, w1, nullptr, nullptr, nullptr, nullptr, dim, a};
+      FmUpd<MI_OPT_SGD> upd{*tab, a};
       return run_segments(plan, pl, src, upd, geo, s);
     }
     case MI_OPT_ADAGRAD_ROWWISE: {
-      MI_REQUIRE(st0 && st1, "%s: row-wise Adagrad needs st0 (V) and st1 (w1) accumulators", who);
       if (!(pow2(geo.lanes) && geo.lanes <= 64)) {
-        mi_set_error("%s: row-wise Adagrad needs dim/%d to be a power of two <= 64", who, geo.vec);
+        mi_set_error("%s: row-wise Adagrad needs dim/4 to be a power of two <= 64", who);
         return MI_ERR_UNSUPPORTED;
       }
-      FmUpd<MI_OPT_ADAGRAD_ROWWISE> upd{V, w1, st0, st1, nullptr, nullptr, dim, a};
+      FmUpd<MI_OPT_ADAGRAD_ROWWISE> upd{*tab, a};
       return run_segments(plan, pl, src, upd, geo, s);
     }
     case MI_OPT_ADAM_TF: {
-      MI_REQUIRE(st0 && st1 && st2 && st3, "%s: Adam needs st0..st3", who);
-      FmUpd<MI_OPT_ADAM_TF> upd{V, w1, st0, st1, st2, st3, dim, a};
+      FmUpd<MI_OPT_ADAM_TF> upd{*tab, a};
       return run_segments(plan, pl, src, upd, geo, s);
     }
     default:

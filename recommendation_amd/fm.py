@@ -6,12 +6,14 @@ blocks - row gather, sort-by-row sparse backward, TensorFlow-form Adam
 (recommendation/code/model_trainer.py:157) - on 26 large tables.
 
 One training step is five entry points of the C ABI and no torch arithmetic:
+  mi_adam_schedule_step the optimizer's scalar state (alpha_t, beta powers), kept on the device
   mi_fm_fwd            gather + pairwise term in registers + BCE loss rows + dL/dlogit
-  mi_embag_bwd_prepare stable sort of (row, position), run detection
+  mi_embag_bwd_prepare stable sort of (row, position)
   mi_fm_bwd_apply      per distinct row: sum_i g_i*(S_i - v) and the fused optimizer
-  mi_fm_bwd_dense      gradients of the dense-feature weights and the bias
-  mi_adam_tf_dense     their update; mi_reduce_sum gives the mean loss
-All buffers are allocated once per batch shape, so a step allocates nothing.
+  mi_fm_dense_step     dense-feature weight / bias gradients, their Adam update, mean loss
+Parameters and optimizer state live in one record per row (ops.FmRecords), so a row's update
+touches one or two 128-byte lines.  All buffers are allocated once per batch shape: a step
+allocates nothing and can be captured in a HIP graph.
 """
 import torch
 
@@ -34,23 +36,35 @@ class FactorizationMachine(object):
         gen = torch.Generator(device=self.device)
         gen.manual_seed(seed)
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.V = torch.randn((self.total_rows, self.dim), generator=gen, **f32).mul_(init_scale)
-        self.w1 = torch.randn((self.total_rows,), generator=gen, **f32).mul_(init_scale)
-        # dense side: wd[n_dense] followed by the bias, one flat buffer so one Adam launch covers both
+        self.table = ops.FmRecords(self.total_rows, self.dim, _OPT[opt], self.device)
+        # initialise V and w1 in place, chunked so the temporary stays small next to a 8 GB table
+        chunk = 1 << 22
+        for lo in range(0, self.total_rows, chunk):
+            hi = min(lo + chunk, self.total_rows)
+            self.table.rec[lo:hi, :self.dim + 1] = torch.randn((hi - lo, self.dim + 1), generator=gen,
+                                                               **f32).mul_(init_scale)
+        # dense side: wd[n_dense] followed by the bias, one flat buffer so one launch covers both
         self.dp = torch.zeros((self.n_dense + 1,), **f32)
         self.dp[:self.n_dense] = torch.randn((self.n_dense,), generator=gen, **f32).mul_(init_scale)
         self.dm, self.dv = torch.zeros_like(self.dp), torch.zeros_like(self.dp)
-        self.state = []
-        if opt == 'adagrad_rowwise':
-            self.state = [torch.zeros((self.total_rows,), **f32), torch.zeros((self.total_rows,), **f32)]
-        elif opt == 'adam_tf':
-            self.state = [torch.zeros_like(self.V), torch.zeros_like(self.V), torch.zeros_like(self.w1),
-                          torch.zeros_like(self.w1)]
-        self._schedule = ops.TFAdamSchedule(lr, beta1, beta2)
+        # tf.train.AdamOptimizer's {alpha_t, beta1_power, beta2_power}, kept on the device so that a
+        # captured graph of the step can be replayed unchanged step after step
+        self.sched = torch.tensor([0.0, 1.0, 1.0, 0.0], **f32)
+        self.steps = 0
         self.err = ops.new_error_word(self.device)
         self._buf_B = None
+        self._graphs = {}
+        self._side = None
 
     # -- views ------------------------------------------------------------------------------
+    @property
+    def V(self):
+        return self.table.V
+
+    @property
+    def w1(self):
+        return self.table.w1
+
     @property
     def wd(self):
         return self.dp[:self.n_dense]
@@ -61,14 +75,13 @@ class FactorizationMachine(object):
 
     def load_state(self, st):
         """Copy parameters from an object with numpy V, w1, wd, bias (the test oracle's state)."""
-        self.V.copy_(torch.from_numpy(st.V))
-        self.w1.copy_(torch.from_numpy(st.w1))
+        self.table.rec[:, :self.dim] = torch.from_numpy(st.V).to(self.device)
+        self.table.rec[:, self.table.off_w1] = torch.from_numpy(st.w1).to(self.device)
         self.dp[:self.n_dense].copy_(torch.from_numpy(st.wd))
         self.dp[self.n_dense] = float(st.bias)
 
     def state_bytes(self):
-        n = self.V.numel() + self.w1.numel()
-        return 4 * (n + sum(s.numel() for s in self.state))
+        return self.table.rec.numel() * 4
 
     # -- buffers ----------------------------------------------------------------------------
     def _buffers(self, ids):
@@ -78,9 +91,8 @@ class FactorizationMachine(object):
             f32 = dict(dtype=torch.float32, device=self.device)
             self.buf = dict(logit=torch.empty((B,), **f32), S=torch.empty((B, self.dim), **f32),
                             loss_rows=torch.empty((B,), **f32), g=torch.empty((B,), **f32))
-            self.dgrad = torch.empty((self.n_dense + 1,), **f32)
             self.loss = torch.empty((1,), **f32)
-            self.plan = ops.SortedPlan(self.toffs, self.T, self.total_rows, ids, bag_len=1)
+            self.plan = ops.SortedPlan(self.toffs, self.T, self.total_rows, ids, bag_len=1, runs=False)
             self._buf_B = key
         return self.buf
 
@@ -89,21 +101,60 @@ class FactorizationMachine(object):
         """logits [B]; with labels also fills loss rows and dL/dlogit of the mean BCE loss."""
         buf = self._buffers(ids)
         B = ids.shape[0]
-        return ops.fm_fwd(self.V, self.w1, self.toffs, ids, dense if self.n_dense else None,
+        return ops.fm_fwd(self.table, self.toffs, ids, dense if self.n_dense else None,
                           self.wd if self.n_dense else None, self.bias, labels, 1.0 / B, self.err, out=buf)
 
-    def train_step(self, ids, dense, labels, check_ids=False):
-        """One pass of the hot path; returns the mean loss as a 1-element device tensor."""
-        B = ids.shape[0]
+    def _step_body(self, ids, dense, labels, streams=None):
+        """The launches of one step.  With ``streams`` (two side streams, used under graph capture)
+        the sort runs beside the forward - it only needs the ids - and the dense-side update beside
+        the sparse one."""
+        main = torch.cuda.current_stream()
+        adam = self.opt == 'adam_tf'
+        if streams:
+            streams[0].wait_stream(main)
+            with torch.cuda.stream(streams[0]):
+                self.plan.prepare(ids)
+        ops.adam_schedule_step(self.sched, self.lr, self.beta1, self.beta2)
         r = self.forward(ids, dense, labels)
-        self.plan.prepare(ids)
-        lr_t = self._schedule.step()
-        lr_sparse = lr_t if self.opt == 'adam_tf' else self.lr
-        ops.fm_bwd_apply(self.plan, r['g'], r['S'], self.V, self.w1, _OPT[self.opt], self.state, lr_sparse,
-                         self.beta1, self.beta2, self.eps)
-        ops.fm_bwd_dense(r['g'], dense if self.n_dense else None, out=self.dgrad)
-        ops.adam_tf_dense(self.dp, self.dm, self.dv, self.dgrad, lr_t, self.beta1, self.beta2, self.eps)
-        ops.reduce_sum(r['loss_rows'], 1.0 / B, out=self.loss)
+        if not streams:
+            self.plan.prepare(ids)
+
+        def dense_side():
+            ops.fm_dense_step(r['g'], dense if self.n_dense else None, r['loss_rows'], self.dp, self.dm, self.dv, 0.0,
+                              self.beta1, self.beta2, self.eps, self.loss, lr_dev=self.sched)
+
+        if streams:
+            streams[1].wait_stream(main)
+            with torch.cuda.stream(streams[1]):
+                dense_side()
+            main.wait_stream(streams[0])
+        ops.fm_bwd_apply(self.plan, self.table, r['g'], r['S'], _OPT[self.opt], self.lr, self.beta1, self.beta2,
+                         self.eps, lr_dev=self.sched if adam else None)
+        if streams:
+            main.wait_stream(streams[1])
+        else:
+            dense_side()
+
+    def train_step(self, ids, dense, labels, check_ids=False, graph=False):
+        """One pass of the hot path; returns the mean loss as a 1-element device tensor.
+        ``graph=True`` replays a HIP graph of the step captured on first use for these input
+        buffers (the inputs must stay at the same addresses; their contents may change)."""
+        self._buffers(ids)
+        if graph:
+            key = (ids.data_ptr(), dense.data_ptr(), labels.data_ptr(), ids.shape[0])
+            g = self._graphs.get(key)
+            if g is None:
+                if self._side is None:
+                    self._side = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step_body(ids, dense, labels, streams=self._side)
+                self._graphs[key] = g
+            g.replay()
+        else:
+            self._step_body(ids, dense, labels)
+        self.steps += 1
         if check_ids:
             ops.check_error_word(self.err, "FM ids")
         return self.loss

@@ -144,8 +144,11 @@ class SortedPlan(object):
     """Device artefacts of ``mi_embag_bwd_prepare`` plus the struct the apply calls take."""
 
     def __init__(self, toffs, T, total_rows, indices, offsets=None, bag_len=None, pool_mode=MI_POOL_SUM,
-                 workspace=None):
+                 workspace=None, runs=True):
+        """``runs=False`` skips run detection (unique_rows / seg_offsets / counts stay unset):
+        the fused apply kernels then find the runs in sorted_rows themselves."""
         _need_cuda(toffs, indices, offsets)
+        self.runs = runs
         dev = indices.device
         self.indices = indices.contiguous()
         self.offsets = offsets
@@ -162,10 +165,10 @@ class SortedPlan(object):
         self.n_entries, self.n_bags, self.bag_len = n, n_bags, bag_len
         self.sorted_rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)  # uint32 bit patterns
         self.perm = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        self.unique_rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        self.seg_offsets = torch.empty(n + 1, dtype=torch.int32, device=dev)
-        self.counts = torch.zeros(2, dtype=torch.int32, device=dev)
-        self.long_list = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        self.unique_rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev) if runs else None
+        self.seg_offsets = torch.empty(n + 1, dtype=torch.int32, device=dev) if runs else None
+        self.counts = torch.zeros(2, dtype=torch.int32, device=dev) if runs else None
+        self.long_list = torch.zeros(n + 2, dtype=torch.int32, device=dev)   # first two ints must start at zero
         ws_bytes = _lib.load().mi_embag_bwd_workspace_bytes(n)
         if workspace is None or workspace.numel() < ws_bytes:
             workspace = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
@@ -195,8 +198,10 @@ class SortedPlan(object):
         pool_mode = self.pool_mode
         self.c = BwdPlan(
             sorted_rows=self.sorted_rows.data_ptr(), perm=self.perm.data_ptr(),
-            unique_rows=self.unique_rows.data_ptr(), seg_offsets=self.seg_offsets.data_ptr(),
-            counts=self.counts.data_ptr(), n_entries=n, n_bags=n_bags,
+            unique_rows=self.unique_rows.data_ptr() if self.runs else None,
+            seg_offsets=self.seg_offsets.data_ptr() if self.runs else None,
+            counts=self.counts.data_ptr() if self.runs else None, n_entries=n, n_bags=n_bags,
+            total_rows=self.total_rows,
             offsets=offsets.data_ptr() if offsets is not None else None, bag_len=bag_len, T=T,
             pool_mode=pool_mode, long_list=self.long_list.data_ptr(), indices=self.indices.data_ptr(),
             idx_bits=_idx_bits(self.indices), table_offsets=toffs.data_ptr())
@@ -334,12 +339,49 @@ def adam_tf_dense(p, m, v, g, lr_t, beta1, beta2, eps):
 
 
 # ----------------------------------------------------------------------------- FM
-def fm_fwd(V, w1, toffs, ids, dense=None, wd=None, bias=None, labels=None, gscale=1.0, err=None, out=None):
+class FmRecords(object):
+    """Row records of an FM (struct mi_fm_table): V[dim], w1 and the optimizer state of both,
+    side by side in one 128-byte-aligned record per global row."""
+
+    def __init__(self, total_rows, dim, opt, device):
+        self.dim, self.opt = int(dim), opt
+        nxt = self.dim
+        self.off_w1 = nxt
+        self.off_vs0 = self.off_vs1 = self.off_ws0 = self.off_ws1 = 0
+        if opt == MI_OPT_ADAGRAD_ROWWISE:
+            self.off_vs0, self.off_ws0 = nxt + 1, nxt + 2
+            nxt += 3
+        elif opt == MI_OPT_ADAM_TF:
+            self.off_ws0, self.off_ws1 = nxt + 1, nxt + 2
+            nxt = -(-(nxt + 3) // 32) * 32          # m and v start on a fresh 128-byte line
+            self.off_vs0, self.off_vs1 = nxt, nxt + self.dim
+            nxt += 2 * self.dim
+        else:
+            nxt += 1
+        self.stride = -(-nxt // 32) * 32            # whole 128-byte lines per record
+        self.rec = torch.zeros((int(total_rows), self.stride), dtype=torch.float32, device=device)
+        self.c = _lib.FmTable(rec=self.rec.data_ptr(), stride=self.stride, dim=self.dim, off_w1=self.off_w1,
+                              off_vs0=self.off_vs0, off_vs1=self.off_vs1, off_ws0=self.off_ws0,
+                              off_ws1=self.off_ws1)
+
+    def ref(self):
+        return ctypes.byref(self.c)
+
+    @property
+    def V(self):
+        return self.rec[:, :self.dim]
+
+    @property
+    def w1(self):
+        return self.rec[:, self.off_w1]
+
+
+def fm_fwd(table, toffs, ids, dense=None, wd=None, bias=None, labels=None, gscale=1.0, err=None, out=None):
     """Returns dict(logit, S, loss_rows, g). ``out`` may hold preallocated buffers of those names."""
-    _need_cuda(V, w1, toffs, ids, dense, wd, bias, labels, err)
+    _need_cuda(table.rec, toffs, ids, dense, wd, bias, labels, err)
     B, T = ids.shape
-    dim = V.shape[1]
-    dev = V.device
+    dim = table.dim
+    dev = table.rec.device
     out = out or {}
     f32 = dict(dtype=torch.float32, device=dev)
     logit = out.get('logit') if out.get('logit') is not None else torch.empty((B,), **f32)
@@ -349,15 +391,14 @@ def fm_fwd(V, w1, toffs, ids, dense=None, wd=None, bias=None, labels=None, gscal
         loss_rows = out.get('loss_rows') if out.get('loss_rows') is not None else torch.empty((B,), **f32)
         g = out.get('g') if out.get('g') is not None else torch.empty((B,), **f32)
     n_dense = dense.shape[1] if dense is not None else 0
-    _lib.call('mi_fm_fwd', _p(V), _p(w1), _p(toffs), T, dim, _p(ids), _idx_bits(ids), B, _p(dense), n_dense,
-              _p(wd), _p(bias), _p(labels), gscale, _p(logit), _p(S), _p(loss_rows), _p(g), _p(err), _stream())
+    _lib.call('mi_fm_fwd', table.ref(), _p(toffs), T, _p(ids), _idx_bits(ids), B, _p(dense), n_dense, _p(wd), _p(bias),
+              _p(labels), gscale, _p(logit), _p(S), _p(loss_rows), _p(g), _p(err), _stream())
     return dict(logit=logit, S=S, loss_rows=loss_rows, g=g)
 
 
-def fm_bwd_apply(plan, g, S, V, w1, opt, state, lr, beta1=0.9, beta2=0.999, eps=1e-8):
-    st = list(state) + [None] * (4 - len(state))
-    _lib.call('mi_fm_bwd_apply', plan.ref(), _p(g), _p(S), V.shape[1], _p(V), _p(w1), opt, _p(st[0]), _p(st[1]),
-              _p(st[2]), _p(st[3]), lr, beta1, beta2, eps, _stream())
+def fm_bwd_apply(plan, table, g, S, opt, lr, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None):
+    _lib.call('mi_fm_bwd_apply', plan.ref(), table.ref(), _p(g), _p(S), opt, lr, _p(lr_dev), beta1, beta2, eps,
+              _stream())
 
 
 def fm_bwd_dense(g, dense, out=None):
@@ -366,3 +407,15 @@ def fm_bwd_dense(g, dense, out=None):
         out = torch.empty((n_dense + 1,), dtype=torch.float32, device=g.device)
     _lib.call('mi_fm_bwd_dense', _p(g), _p(dense), n_dense, g.numel(), _p(out), _stream())
     return out
+
+
+def fm_dense_step(g, dense, loss_rows, dp, dm, dv, lr_t, beta1, beta2, eps, loss_out, lr_dev=None):
+    """Dense-side gradients + TensorFlow-form Adam on dp + mean loss, one launch."""
+    n_dense = dense.shape[1] if dense is not None else 0
+    _lib.call('mi_fm_dense_step', _p(g), _p(dense), n_dense, g.numel(), _p(loss_rows), _p(dp), _p(dm), _p(dv), lr_t,
+              _p(lr_dev), beta1, beta2, eps, _p(loss_out), _stream())
+
+
+def adam_schedule_step(sched, lr, beta1, beta2):
+    """Advance the device-resident {alpha_t, beta1_power, beta2_power} by one optimizer step."""
+    _lib.call('mi_adam_schedule_step', _p(sched), lr, beta1, beta2, _stream())

@@ -362,8 +362,10 @@ def test_fm_forward(dev, dim, idx_dtype):
     B = 515
     ids, dense, labels = ofm.synthetic_batch(B, rows, 13, seed=4, idx_dtype=idx_dtype)
     err = ops.new_error_word(dev)
-    r = ops.fm_fwd(torch.from_numpy(st.V).to(dev), torch.from_numpy(st.w1).to(dev),
-                   torch.from_numpy(st.toffs).to(dev), torch.from_numpy(ids).to(dev),
+    table = ops.FmRecords(int(st.toffs[-1]), dim, ops.MI_OPT_ADAM_TF, dev)
+    table.rec[:, :dim] = torch.from_numpy(st.V).to(dev)
+    table.rec[:, table.off_w1] = torch.from_numpy(st.w1).to(dev)
+    r = ops.fm_fwd(table, torch.from_numpy(st.toffs).to(dev), torch.from_numpy(ids).to(dev),
                    torch.from_numpy(dense).to(dev), torch.from_numpy(st.wd).to(dev),
                    torch.tensor([st.bias], device=dev), torch.from_numpy(labels).to(dev), 1.0 / B, err)
     ops.check_error_word(err)
@@ -400,3 +402,87 @@ def test_fm_train_step(dev, opt, dist):
     assert rel_err(fm.w1.cpu().numpy(), ref.w1) <= tol
     assert rel_err(fm.wd.cpu().numpy(), ref.wd) <= tol
     assert abs(float(fm.bias.item()) - float(ref.bias)) <= 1e-6
+
+
+@pytest.mark.parametrize("B", [700, 3000])
+def test_runless_plan_matches_the_run_arrays_path(dev, B):
+    """No unique_rows / seg_offsets in the plan: the apply kernels find the runs in sorted_rows.
+    B=700: every table sorted in LDS (3500 entries per table, padding ends each table's block);
+    B=3000: the global multi-pass sort (15000 per table).  Both must give the compacted-run
+    path's sums (<= 1e-6: the summation trees differ where a run crosses a wave) and be bitwise
+    reproducible from call to call, long runs included."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(12)
+    dim = 16
+    rows, T, _, L, w, toffs, _, _ = _bag_problem(rng, dim, "sum")
+    ids = np.stack([rng.integers(-1, r, size=(B, L)) for r in rows], axis=1).astype(np.int32)
+    ids[:, 0, :] = rng.integers(0, 3, size=(B, L))
+    grad = rng.standard_normal((B, T * dim)).astype(np.float32)
+    total = int(toffs[-1])
+    g = torch.from_numpy(grad).to(dev)
+    outs = []
+    for runs in (True, False, False):
+        plan = ops.SortedPlan(torch.from_numpy(toffs).to(dev), T, total, torch.from_numpy(ids).to(dev), bag_len=L,
+                              runs=runs)
+        outs.append(ops.bwd_dense_grad(plan, g, dim, total).cpu().numpy())
+        assert plan.long_list[:2].tolist() == [0, 0]          # the queue is left empty for the next call
+    assert np.array_equal(outs[1], outs[2])
+    assert rel_err(outs[1], outs[0]) <= 1e-6
+    want = oe.dense_grad(total, dim, oe.row_grads(toffs, T, ids, grad, dim, bag_len=L))
+    assert rel_err(outs[1], want) <= RTOL
+
+
+@pytest.mark.parametrize("B,L", [(8192, 1), (1000, 7), (1, 1)])
+def test_per_table_lds_sort_is_the_global_stable_sort(dev, B, L):
+    """Without padding the one-launch per-table sort must equal numpy's stable argsort by
+    (global row, position) bit for bit."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(13)
+    rows = [3, 1000, 50, 100000, 10131227, 24]
+    T = len(rows)
+    toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    ids = np.stack([rng.integers(0, r, size=(B, L)) for r in rows], axis=1).astype(np.int64)
+    plan = ops.SortedPlan(torch.from_numpy(toffs).to(dev), T, int(toffs[-1]), torch.from_numpy(ids).to(dev),
+                          bag_len=L, runs=False)
+    want_rows, want_perm, _, _ = oe.prepare(toffs, T, ids, bag_len=L)
+    assert np.array_equal(plan.sorted_rows.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, want_rows)
+    assert np.array_equal(plan.perm.cpu().numpy(), want_perm)
+
+
+def test_fm_record_layout_is_checked(dev):
+    from recommendation_amd import ops
+    t = ops.FmRecords(10, 16, ops.MI_OPT_ADAM_TF, dev)
+    assert t.stride % 32 == 0 and t.off_vs0 % 4 == 0 and t.off_vs1 == t.off_vs0 + 16
+    t.c.off_vs1 = t.off_vs0 + 4                       # m and v overlap
+    plan = ops.SortedPlan(ops.table_offsets([10], dev), 1, 10, torch.zeros((4, 1), dtype=torch.int32, device=dev),
+                          bag_len=1, runs=False)
+    z = torch.zeros((4, 16), device=dev)
+    with pytest.raises(ops.MiError):
+        ops.fm_bwd_apply(plan, t, z[:, 0].contiguous(), z, ops.MI_OPT_ADAM_TF, 0.1)
+
+
+@pytest.mark.parametrize("opt", ["adagrad_rowwise", "adam_tf"])
+def test_fm_graph_replay_equals_eager_bitwise(dev, opt):
+    """The captured step (sort beside the forward, dense side beside the sparse update, step size
+    read from the device-resident schedule) must leave exactly the bits the eager step leaves."""
+    from recommendation_amd.fm import FactorizationMachine
+    rows = [1460, 583, 30000, 305, 24, 3, 10, 4, 18, 15, 105, 27, 2173]
+    ref = ofm.State(rows, 16, 13, seed=5, opt=opt)
+    a = FactorizationMachine(rows, 16, 13, device=dev, opt=opt, lr=1e-2)
+    b = FactorizationMachine(rows, 16, 13, device=dev, opt=opt, lr=1e-2)
+    a.load_state(ref)
+    b.load_state(ref)
+    ids, dense, labels = ofm.synthetic_batch(4096, rows, 13, seed=21, dist='zipf')
+    bufs = (torch.from_numpy(ids).to(dev), torch.from_numpy(dense).to(dev), torch.from_numpy(labels).to(dev))
+    for step in range(4):
+        ids2, dense2, labels2 = ofm.synthetic_batch(4096, rows, 13, seed=30 + step, dist='zipf')
+        for dst, src in zip(bufs, (ids2, dense2, labels2)):
+            dst.copy_(torch.from_numpy(src))          # same buffers, new contents
+        la = a.train_step(*bufs).clone()
+        lb = b.train_step(*bufs, graph=True).clone()
+        assert torch.equal(la, lb)
+    assert len(b._graphs) == 1
+    assert torch.equal(a.table.rec, b.table.rec) and torch.equal(a.dp, b.dp) and torch.equal(a.sched, b.sched)
+    # and the device-resident schedule is TensorFlow's fp32 schedule
+    alpha, _, _ = oe.tf_adam_scalars(1e-2, 0.9, 0.999, 4)
+    assert float(a.sched[0].item()) == np.float32(alpha)
