@@ -124,16 +124,19 @@ __global__ __launch_bounds__(SORT_BLOCK) void scatter_kernel(const uint32_t* __r
     const int idx = wbase + j * MI_WAVE + lane;
     const bool valid = idx < n;
     const uint32_t d = (key[j] >> shift) & (RADIX - 1);
-    unsigned long long mask = __ballot(valid);
+    // lanes holding the same digit (see table_sort_kernel for the bit trick)
+    const unsigned long long vb = __ballot(valid);
+    uint32_t mlo = (uint32_t) vb, mhi = (uint32_t) (vb >> 32);
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const unsigned long long bal = __ballot(bit);
-      mask &= bit ? bal : ~bal;
+      const int x = ((int) (d << (31 - b))) >> 31;
+      const unsigned long long bal = __ballot(x != 0);
+      mlo &= ~((uint32_t) bal ^ (uint32_t) x);
+      mhi &= ~((uint32_t) (bal >> 32) ^ (uint32_t) x);
     }
-    const uint32_t before = (uint32_t) __popcll(mask & lt);
+    const uint32_t before = (uint32_t) (__popc(mlo & (uint32_t) lt) + __popc(mhi & (uint32_t) (lt >> 32)));
     const uint32_t old = cnt[w][d];
-    if (valid && before == 0) cnt[w][d] = old + (uint32_t) __popcll(mask);
+    if (valid && before == 0) cnt[w][d] = old + (uint32_t) (__popc(mlo) + __popc(mhi));
     loc[j] = old + before;
   }
   __syncthreads();
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(TS_THREADS) void table_sort_kernel(const int64_t* _
   __shared__ uint32_t vbuf[2][TS_MAX];
   __shared__ uint32_t cnt[TS_WAVES][TS_RADIX];
   __shared__ uint32_t dbase[TS_RADIX];
+  __shared__ uint32_t qsum[4][TS_RADIX];
   __shared__ uint32_t wsum[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int t = blockIdx.x;
@@ -448,28 +452,53 @@ __global__ __launch_bounds__(TS_THREADS) void table_sort_kernel(const int64_t* _
       const bool valid = e < n;
       key[j] = valid ? kbuf[cur][e] : 0xFFFFFFFFu;
       const uint32_t d = (key[j] >> shift) & (TS_RADIX - 1);
-      unsigned long long mask = __ballot(valid);
+      // lanes holding the same digit: AND over the 8 digit bits of "lanes whose bit equals mine".
+      // x = 0 / ~0 (bit clear / set), so ~(ballot ^ x) is that set; the two 32-bit halves are kept
+      // apart (sign-extending bit extract, xnor, and: 6 vector instructions per bit).
+      const unsigned long long vb = __ballot(valid);
+      uint32_t mlo = (uint32_t) vb, mhi = (uint32_t) (vb >> 32);
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long bal = __ballot(bit);
-        mask &= bit ? bal : ~bal;
+        const int x = ((int) (d << (31 - b))) >> 31;
+        const unsigned long long bal = __ballot(x != 0);
+        mlo &= ~((uint32_t) bal ^ (uint32_t) x);
+        mhi &= ~((uint32_t) (bal >> 32) ^ (uint32_t) x);
       }
-      const uint32_t before = (uint32_t) __popcll(mask & lt);
+      const uint32_t before = (uint32_t) (__popc(mlo & (uint32_t) lt) + __popc(mhi & (uint32_t) (lt >> 32)));
       const uint32_t old = cnt[w][d];
-      if (valid && before == 0) cnt[w][d] = old + (uint32_t) __popcll(mask);
+      if (valid && before == 0) cnt[w][d] = old + (uint32_t) (__popc(mlo) + __popc(mhi));
       loc[j] = old + before;
     }
     __syncthreads();
     // digit totals -> per-wave running bases, then an exclusive scan of the 256 totals
-    uint32_t total = 0;
-    if (tid < TS_RADIX) {
+    // thread (q, d) = (tid >> 8, tid & 255) scans waves 4q..4q+3 of digit d; the four partial
+    // totals of a digit are then chained through LDS
+    uint32_t part = 0;
+    {
+      const int dq = tid & (TS_RADIX - 1), q4 = (tid >> 8) * 4;
 #pragma unroll
-      for (int i = 0; i < TS_WAVES; ++i) {
-        const uint32_t c = cnt[i][tid];
-        cnt[i][tid] = total;
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t c = cnt[q4 + i][dq];
+        cnt[q4 + i][dq] = part;
+        part += c;
+      }
+      qsum[tid >> 8][dq] = part;
+    }
+    __syncthreads();
+    uint32_t total = 0;
+    {
+      const int dq = tid & (TS_RADIX - 1), q = tid >> 8;
+      uint32_t before_q = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t c = qsum[i][dq];
+        if (i < q) before_q += c;
         total += c;
       }
+      const int q4 = q * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cnt[q4 + i][dq] += before_q;
+      if (tid >= TS_RADIX) total = 0;
     }
     uint32_t inc = total;
 #pragma unroll
