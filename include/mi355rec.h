@@ -215,9 +215,10 @@ int mi_colsum(const float* x, int64_t ld, int64_t B, int N, float* out, void* st
 int mi_reduce_sum(const float* x, int64_t n, float scale, float* out, void* stream);
 
 /* tf.train.AdamOptimizer applied densely to a flat fp32 buffer (model_trainer.py:157-158):
- * m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2; p -= lr_t*m/(sqrt(v)+eps). */
+ * m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2; p -= lr_t*m/(sqrt(v)+eps).  lr_t = alpha_t of the step;
+ * when lr_dev != NULL it is read from lr_dev[0] on the device (mi_adam_schedule_step). */
 int mi_adam_tf_dense(float* p, float* m, float* v, const float* g, int64_t n, float lr_t,
-                     float beta1, float beta2, float eps, void* stream);
+                     const float* lr_dev, float beta1, float beta2, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * FM (not in the reference; extension named by the benchmark definition).
@@ -260,12 +261,13 @@ int mi_fm_fwd(const mi_fm_table* tab, const int64_t* table_offsets, int T, const
 /* FM backward fused with the sparse update of V and w1.  For distinct row r with run
  * {b_i}: dV[r] = sum_i g[b_i]*S[b_i] - V[r]*sum_i g[b_i];  dw1[r] = sum_i g[b_i].
  * plan comes from mi_embag_bwd_prepare on ids (bag_len 1); its run arrays may be NULL.
+ * The sample of entry p is p / T, or entry_sample[p] when entry_sample != NULL (sharded tables).
  * lr is alpha_t for MI_OPT_ADAM_TF (see mi_adam_tf_dense); when lr_dev != NULL the step
  * size is read from lr_dev[0] on the device instead (see mi_adam_schedule_step), which lets a
  * captured HIP graph be replayed step after step. */
 int mi_fm_bwd_apply(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* g,
-                    const float* S, int opt, float lr, const float* lr_dev, float beta1,
-                    float beta2, float eps, void* stream);
+                    const float* S, const int32_t* entry_sample, int opt, float lr,
+                    const float* lr_dev, float beta1, float beta2, float eps, void* stream);
 
 /* Dense-side FM gradients: dwd[j] = sum_b g[b]*dense[b][j], dbias = sum_b g[b]
  * (fixed-order sums).  out = dwd[n_dense] followed by dbias. */
@@ -284,6 +286,56 @@ int mi_fm_dense_step(const float* g, const float* dense, int n_dense, int64_t B,
  * caller to {0, 1, 1}.  One call = one optimizer step: both powers are multiplied by their
  * beta and alpha_t = lr*sqrt(1-beta2_power)/(1-beta1_power), all in fp32. */
 int mi_adam_schedule_step(float* sched, float lr, float beta1, float beta2, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Row-wise sharded tables (N ranks, one process per GPU).  Global row r = table_offsets[t] + id
+ * lives on rank r % N as local row r / N.  Replaces the parameter-server variable traffic of
+ * model_trainer.py:124-136 (every variable read and every Adam apply a gRPC hop to the ps task).
+ * The three collectives of a step are issued by the host between these calls, all with
+ * fixed sizes (nothing on the host depends on the ids):
+ *   all-to-all  send[N][blk] int32            requester -> owner   blk = mi_shard_block_ints(B,T)
+ *   all-to-all  partial[N][B][dim+2] fp32      owner -> requester
+ *   all-gather  X[B][ld] fp32 -> X_all[N*B][ld]
+ * ---------------------------------------------------------------------------------- */
+
+/* Ints per rank pair in the row exchange: B+1 offsets followed by room for B*T rows. */
+int64_t mi_shard_block_ints(int64_t B, int T);
+
+/* Requester: route the ids of a batch [B][T].  send[N][blk]: block d holds, for destination
+ * rank d, bag_off[0..B] (exclusive offsets of each sample's entries; [B] = their number)
+ * followed by the local rows grouped by sample, fields in field order. */
+int mi_shard_route(const int64_t* table_offsets, int T, const void* ids, int idx_bits, int64_t B,
+                   int n_ranks, int32_t* send, int32_t* err, void* stream);
+
+/* Owner: recv[N][blk] = the blocks received from every rank.  Writes
+ *   partial[N][B][dim+2]  { sum v (dim), sum |v|^2, sum w1 } per (source rank, sample)
+ *   rows_out[n]           the received rows back to back (source rank, sample, field order)
+ *   entry_sample[n]       s*B + b of every received entry
+ *   n_out[0]              n, at most N*B*T (size rows_out / entry_sample for that) */
+int mi_fm_partial_fwd(const mi_fm_table* tab, int64_t local_rows, const int32_t* recv,
+                      int n_ranks, int64_t B, int T, float* partial, int32_t* rows_out,
+                      int32_t* entry_sample, int32_t* n_out, int32_t* err, void* stream);
+
+/* Requester: partials[N][B][dim+2] (one slab per owner, summed in rank order) + dense part +
+ * bias -> one row per sample of what the other ranks need,
+ *   X[b] = [ S (dim) | g = (sigmoid(logit)-y)*gscale | BCE loss row | dense[b] (n_dense) | 0.. ]
+ * with ld floats per row (ld % 4 == 0, ld >= dim+2+n_dense).  logit may be NULL. */
+int mi_fm_combine(const float* partials, int n_ranks, int64_t B, int dim, const float* dense,
+                  int n_dense, const float* wd, const float* bias, const float* labels,
+                  float gscale, float* logit, float* X, int ld, void* stream);
+
+/* mi_fm_bwd_apply reading g and S from rows laid out as mi_fm_combine writes them
+ * (X_all after the all-gather); entry_sample indexes rows of X. */
+int mi_fm_bwd_apply_rows(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* X, int ld,
+                         const int32_t* entry_sample, int opt, float lr, const float* lr_dev,
+                         float beta1, float beta2, float eps, void* stream);
+
+/* mi_fm_dense_step over n rows laid out as mi_fm_combine writes them: every replica computes
+ * the dense-side gradients of ALL N*B samples itself (same order on every rank, so replicas
+ * stay bit-identical without an all-reduce); loss_out[0] = mean of the n loss rows. */
+int mi_fm_dense_step_rows(const float* X, int ld, int dim, int n_dense, int64_t n, float* dp,
+                          float* dm, float* dv, float lr_t, const float* lr_dev, float beta1,
+                          float beta2, float eps, float* loss_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -64,14 +64,22 @@ _SIGNATURES = {
     'mi_hit_rows': (c_int, [P, P, c_int64, c_int, P, P]),
     'mi_colsum': (c_int, [P, c_int64, c_int64, c_int, P, P]),
     'mi_reduce_sum': (c_int, [P, c_int64, c_float, P, P]),
-    'mi_adam_tf_dense': (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P]),
+    'mi_adam_tf_dense': (c_int, [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, P]),
     'mi_fm_fwd': (c_int, [POINTER(FmTable), P, c_int, P, c_int, c_int64, P, c_int, P, P, P, c_float, P, P, P, P, P,
                           P]),
-    'mi_fm_bwd_apply': (c_int, [POINTER(BwdPlan), POINTER(FmTable), P, P, c_int, c_float, P, c_float, c_float,
+    'mi_fm_bwd_apply': (c_int, [POINTER(BwdPlan), POINTER(FmTable), P, P, P, c_int, c_float, P, c_float, c_float,
                                 c_float, P]),
     'mi_fm_bwd_dense': (c_int, [P, P, c_int, c_int64, P, P]),
     'mi_fm_dense_step': (c_int, [P, P, c_int, c_int64, P, P, P, P, c_float, P, c_float, c_float, c_float, P, P]),
     'mi_adam_schedule_step': (c_int, [P, c_float, c_float, c_float, P]),
+    'mi_shard_block_ints': (c_int64, [c_int64, c_int]),
+    'mi_shard_route': (c_int, [P, c_int, P, c_int, c_int64, c_int, P, P, P]),
+    'mi_fm_partial_fwd': (c_int, [POINTER(FmTable), c_int64, P, c_int, c_int64, c_int, P, P, P, P, P, P]),
+    'mi_fm_combine': (c_int, [P, c_int, c_int64, c_int, P, c_int, P, P, P, c_float, P, P, c_int, P]),
+    'mi_fm_bwd_apply_rows': (c_int, [POINTER(BwdPlan), POINTER(FmTable), P, c_int, P, c_int, c_float, P, c_float,
+                                     c_float, c_float, P]),
+    'mi_fm_dense_step_rows': (c_int, [P, c_int, c_int, c_int, c_int64, P, P, P, c_float, P, c_float, c_float,
+                                      c_float, P, P]),
 }
 
 EXPORTS = tuple(sorted(_SIGNATURES))

@@ -176,8 +176,8 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_sum_kernel(const float* __re
 }
 
 __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
-                                                     const float* __restrict__ g, int64_t n, float lr_t, float b1,
-                                                     float b2, float eps) {
+                                                     const float* __restrict__ g, int64_t n, float lr_t,
+                                                     const float* __restrict__ lr_dev, float b1, float b2, float eps) {
   const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float gi = g[i];
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, flo
   const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
   m[i] = mi;
   v[i] = vi;
-  p[i] -= (mi * lr_t) / (sqrtf(vi) + eps);
+  p[i] -= (mi * (lr_dev ? lr_dev[0] : lr_t)) / (sqrtf(vi) + eps);
 }
 
 int splits_for(int64_t B) { return (int) mi_cdiv(B > 0 ? B : 1, ROWS_PER_SPLIT); }
@@ -276,12 +276,12 @@ extern "C" int mi_reduce_sum(const float* x, int64_t n, float scale, float* out,
   return MI_OK;
 }
 
-extern "C" int mi_adam_tf_dense(float* p, float* m, float* v, const float* g, int64_t n, float lr_t, float beta1,
-                                float beta2, float eps, void* stream) {
+extern "C" int mi_adam_tf_dense(float* p, float* m, float* v, const float* g, int64_t n, float lr_t,
+                                const float* lr_dev, float beta1, float beta2, float eps, void* stream) {
   MI_REQUIRE(p && m && v && g && n >= 0, "mi_adam_tf_dense: bad arguments");
   if (n == 0) return MI_OK;
   hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned) mi_cdiv(n, 256)), dim3(256), 0, (hipStream_t) stream, p, m, v, g, n,
-                     lr_t, beta1, beta2, eps);
+                     lr_t, lr_dev, beta1, beta2, eps);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -123,9 +123,12 @@ __device__ __forceinline__ float block_sum_1024(float acc, float* sh) {
 // Workgroup j < n_dense: dwd[j] = sum_b g[b]*dense[b][j]; j == n_dense: dbias = sum_b g[b];
 // j == n_dense+1 (only when loss_rows != NULL): mean of the loss rows.  Fixed summation
 // order.  When dp != NULL the gradient is consumed in place by TensorFlow-form Adam on dp[j].
-__global__ __launch_bounds__(1024) void fm_dense_kernel(const float* __restrict__ g, const float* __restrict__ dense,
+// g, dense rows and loss rows are g_ld, dense_ld and loss_ld floats apart (1, n_dense, 1 for plain arrays).
+__global__ __launch_bounds__(1024) void fm_dense_kernel(const float* __restrict__ g, int64_t g_ld,
+                                                       const float* __restrict__ dense, int64_t dense_ld,
                                                        int n_dense, int64_t B, float* __restrict__ grad_out,
-                                                       const float* __restrict__ loss_rows, float* __restrict__ dp,
+                                                       const float* __restrict__ loss_rows, int64_t loss_ld,
+                                                       float* __restrict__ dp,
                                                        float* __restrict__ dm, float* __restrict__ dv, float lr_t,
                                                        const float* __restrict__ lr_dev, float b1, float b2,
                                                        float eps, float* __restrict__ loss_out) {
@@ -133,11 +136,11 @@ __global__ __launch_bounds__(1024) void fm_dense_kernel(const float* __restrict_
   const int j = blockIdx.x;
   float acc = 0.f;
   if (j < n_dense) {
-    for (int64_t b = threadIdx.x; b < B; b += 1024) acc = fmaf(g[b], dense[b * n_dense + j], acc);
+    for (int64_t b = threadIdx.x; b < B; b += 1024) acc = fmaf(g[b * g_ld], dense[b * dense_ld + j], acc);
   } else if (j == n_dense) {
-    for (int64_t b = threadIdx.x; b < B; b += 1024) acc += g[b];
+    for (int64_t b = threadIdx.x; b < B; b += 1024) acc += g[b * g_ld];
   } else {
-    for (int64_t b = threadIdx.x; b < B; b += 1024) acc += loss_rows[b];
+    for (int64_t b = threadIdx.x; b < B; b += 1024) acc += loss_rows[b * loss_ld];
   }
   const float tot = block_sum_1024(acc, sh);
   if (threadIdx.x != 0) return;
@@ -254,8 +257,8 @@ extern "C" int mi_adam_schedule_step(float* sched, float lr, float beta1, float 
 extern "C" int mi_fm_bwd_dense(const float* g, const float* dense, int n_dense, int64_t B, float* out,
                                void* stream) {
   MI_REQUIRE(g && out && n_dense >= 0 && B >= 0 && (n_dense == 0 || dense), "mi_fm_bwd_dense: bad arguments");
-  hipLaunchKernelGGL(fm_dense_kernel, dim3(n_dense + 1), dim3(1024), 0, (hipStream_t) stream, g, dense, n_dense, B, out,
-                     (const float*) nullptr, (float*) nullptr, (float*) nullptr, (float*) nullptr, 0.f,
+  hipLaunchKernelGGL(fm_dense_kernel, dim3(n_dense + 1), dim3(1024), 0, (hipStream_t) stream, g, (int64_t) 1, dense,
+                     (int64_t) n_dense, n_dense, B, out, (const float*) nullptr, (int64_t) 1, (float*) nullptr, (float*) nullptr, (float*) nullptr, 0.f,
                      (const float*) nullptr, 0.f, 0.f, 0.f, (float*) nullptr);
   MI_LAUNCH_CHECK();
   return MI_OK;
@@ -267,7 +270,20 @@ extern "C" int mi_fm_dense_step(const float* g, const float* dense, int n_dense,
   MI_REQUIRE(g && dp && dm && dv && n_dense >= 0 && B >= 1 && (n_dense == 0 || dense), "mi_fm_dense_step: bad arguments");
   MI_REQUIRE((loss_rows == nullptr) == (loss_out == nullptr), "mi_fm_dense_step: loss_rows and loss_out go together");
   hipLaunchKernelGGL(fm_dense_kernel, dim3(n_dense + 1 + (loss_rows ? 1 : 0)), dim3(1024), 0, (hipStream_t) stream, g,
-                     dense, n_dense, B, (float*) nullptr, loss_rows, dp, dm, dv, lr_t, lr_dev, beta1, beta2, eps, loss_out);
+                     (int64_t) 1, dense, (int64_t) n_dense, n_dense, B, (float*) nullptr, loss_rows, (int64_t) 1, dp, dm, dv,
+                     lr_t, lr_dev, beta1, beta2, eps, loss_out);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_fm_dense_step_rows(const float* X, int ld, int dim, int n_dense, int64_t n, float* dp, float* dm,
+                                     float* dv, float lr_t, const float* lr_dev, float beta1, float beta2, float eps,
+                                     float* loss_out, void* stream) {
+  MI_REQUIRE(X && dp && dm && dv && loss_out && n_dense >= 0 && n >= 1 && dim >= 1 && ld >= dim + 2 + n_dense,
+             "mi_fm_dense_step_rows: bad arguments");
+  hipLaunchKernelGGL(fm_dense_kernel, dim3(n_dense + 2), dim3(1024), 0, (hipStream_t) stream, X + dim, (int64_t) ld,
+                     X + dim + 2, (int64_t) ld, n_dense, n, (float*) nullptr, X + dim + 1, (int64_t) ld, dp, dm, dv, lr_t,
+                     lr_dev, beta1, beta2, eps, loss_out);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -105,16 +105,19 @@ struct BagGradSrc {
   }
 };
 
-// FM: entry of sample b contributes g[b]*S[b] (vector) and g[b] (scalar); bag_len == 1
+// FM: entry of sample b contributes g[b]*S[b] (vector) and g[b] (scalar); bag_len == 1.
+// The sample of entry p is p / T, or entry_sample[p] when given (sharded tables: the entries an
+// owner received from all ranks, each tagged with its requester's sample).
 struct FmSrc {
   const float* g;
   const float* S;
-  int dim;
+  int g_ld, S_ld;  // floats between consecutive samples (1 and dim when g and S are separate arrays)
+  const int32_t* entry_sample;
   template <int VEC>
   __device__ __forceinline__ void load(const PlanDev& pl, int p, int c, float* o, float& sc) const {
-    const int b = p / pl.T;
-    const float gb = g[b];
-    ldv<VEC>(S + (int64_t) b * dim + c * VEC, o);
+    const int b = entry_sample ? entry_sample[p] : p / pl.T;
+    const float gb = g[(int64_t) b * g_ld];
+    ldv<VEC>(S + (int64_t) b * S_ld + c * VEC, o);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) o[k] *= gb;
     sc = gb;
@@ -774,10 +777,9 @@ extern "C" int mi_embag_bwd_apply_adam_dense_tf(const mi_bwd_plan* plan, const f
   return MI_OK;
 }
 
-extern "C" int mi_fm_bwd_apply(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* g, const float* S,
-                               int opt, float lr, const float* lr_dev, float beta1, float beta2, float eps,
-                               void* stream) {
-  const char* who = "mi_fm_bwd_apply";
+static int fm_bwd_apply_impl(const char* who, const mi_bwd_plan* plan, const mi_fm_table* tab, const float* g,
+                             int g_ld, const float* S, int S_ld, const int32_t* entry_sample, int opt, float lr,
+                             const float* lr_dev, float beta1, float beta2, float eps, void* stream) {
   PlanDev pl;
   int rc = check_plan(plan, &pl, false, who);
   if (rc) return rc;
@@ -786,11 +788,12 @@ extern "C" int mi_fm_bwd_apply(const mi_bwd_plan* plan, const mi_fm_table* tab, 
   if (rc) return rc;
   MI_REQUIRE(!plan->offsets && plan->bag_len == 1 && plan->pool_mode == MI_POOL_SUM,
              "%s: FM takes one id per field (bag_len 1, sum)", who);
-  MI_REQUIRE(al16(S), "%s: S must be 16-byte aligned", who);
+  MI_REQUIRE(al16(S) && S_ld % 4 == 0 && S_ld >= tab->dim && g_ld >= 1,
+             "%s: S rows must be 16-byte aligned and at least dim floats apart", who);
   Geometry geo;
   rc = geometry(tab->dim, true, &geo);
   if (rc) return rc;
-  FmSrc src{g, S, tab->dim};
+  FmSrc src{g, S, g_ld, S_ld, entry_sample};
   OptArgs a{lr, beta1, beta2, eps, lr_dev};
   hipStream_t s = (hipStream_t) stream;
   switch (opt) {
@@ -814,4 +817,20 @@ extern "C" int mi_fm_bwd_apply(const mi_bwd_plan* plan, const mi_fm_table* tab, 
       mi_set_error("%s: unknown optimizer %d", who, opt);
       return MI_ERR_INVALID_ARG;
   }
+}
+
+extern "C" int mi_fm_bwd_apply(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* g, const float* S,
+                               const int32_t* entry_sample, int opt, float lr, const float* lr_dev, float beta1,
+                               float beta2, float eps, void* stream) {
+  MI_REQUIRE(tab, "mi_fm_bwd_apply: null table");
+  return fm_bwd_apply_impl("mi_fm_bwd_apply", plan, tab, g, 1, S, tab->dim, entry_sample, opt, lr, lr_dev, beta1,
+                           beta2, eps, stream);
+}
+
+extern "C" int mi_fm_bwd_apply_rows(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* X, int ld,
+                                    const int32_t* entry_sample, int opt, float lr, const float* lr_dev, float beta1,
+                                    float beta2, float eps, void* stream) {
+  MI_REQUIRE(tab && X && entry_sample, "mi_fm_bwd_apply_rows: null pointer");
+  return fm_bwd_apply_impl("mi_fm_bwd_apply_rows", plan, tab, X + tab->dim, ld, X, ld, entry_sample, opt, lr, lr_dev,
+                           beta1, beta2, eps, stream);
 }

@@ -192,6 +192,17 @@ class SortedPlan(object):
                   _p(self.workspace), self.workspace.numel(), _stream())
         return self
 
+    def prepare_prefix(self, n):
+        """Sort only the first ``n`` entries of the plan's index buffer (fixed bag length, n a
+        multiple of it): for callers whose entry count changes from step to step below a known
+        capacity.  Allocates nothing."""
+        cap = self.indices.numel()
+        if self.offsets is not None or n < 1 or n > cap or n % max(self.bag_len, 1):
+            raise MiError("SortedPlan.prepare_prefix: n=%d outside 1..%d or not whole bags" % (n, cap))
+        self.n_entries, self.n_bags = n, n // max(self.bag_len, 1)
+        self._bind()
+        return self.prepare()
+
     def _bind(self):
         n, n_bags, bag_len, T, offsets, toffs = (self.n_entries, self.n_bags, self.bag_len, self.T, self.offsets,
                                                  self.toffs)
@@ -332,10 +343,11 @@ def reduce_sum(x, scale=1.0, out=None):
     return out
 
 
-def adam_tf_dense(p, m, v, g, lr_t, beta1, beta2, eps):
+def adam_tf_dense(p, m, v, g, lr_t, beta1, beta2, eps, lr_dev=None):
     _need_cuda(p, m, v, g)
     assert p.is_contiguous() and m.is_contiguous() and v.is_contiguous() and g.is_contiguous()
-    _lib.call('mi_adam_tf_dense', _p(p), _p(m), _p(v), _p(g), p.numel(), lr_t, beta1, beta2, eps, _stream())
+    _lib.call('mi_adam_tf_dense', _p(p), _p(m), _p(v), _p(g), p.numel(), lr_t, _p(lr_dev), beta1, beta2, eps,
+              _stream())
 
 
 # ----------------------------------------------------------------------------- FM
@@ -396,9 +408,9 @@ def fm_fwd(table, toffs, ids, dense=None, wd=None, bias=None, labels=None, gscal
     return dict(logit=logit, S=S, loss_rows=loss_rows, g=g)
 
 
-def fm_bwd_apply(plan, table, g, S, opt, lr, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None):
-    _lib.call('mi_fm_bwd_apply', plan.ref(), table.ref(), _p(g), _p(S), opt, lr, _p(lr_dev), beta1, beta2, eps,
-              _stream())
+def fm_bwd_apply(plan, table, g, S, opt, lr, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None, entry_sample=None):
+    _lib.call('mi_fm_bwd_apply', plan.ref(), table.ref(), _p(g), _p(S), _p(entry_sample), opt, lr, _p(lr_dev), beta1,
+              beta2, eps, _stream())
 
 
 def fm_bwd_dense(g, dense, out=None):
@@ -419,3 +431,49 @@ def fm_dense_step(g, dense, loss_rows, dp, dm, dv, lr_t, beta1, beta2, eps, loss
 def adam_schedule_step(sched, lr, beta1, beta2):
     """Advance the device-resident {alpha_t, beta1_power, beta2_power} by one optimizer step."""
     _lib.call('mi_adam_schedule_step', _p(sched), lr, beta1, beta2, _stream())
+
+
+# ----------------------------------------------------------------------------- sharded tables
+def shard_block_ints(B, T):
+    """Ints per rank pair in the row exchange (B+1 offsets, then room for B*T rows)."""
+    return B + 1 + B * T
+
+
+def shard_row_floats(dim, n_dense):
+    """Floats per sample in the gathered rows [S | g | loss | dense | pad], a multiple of 4."""
+    return -(-(dim + 2 + n_dense) // 4) * 4
+
+
+def shard_route(toffs, ids, n_ranks, send, err=None):
+    B, T = ids.shape
+    if send.numel() < n_ranks * shard_block_ints(B, T):
+        raise MiError("shard_route: send buffer too small")
+    _lib.call('mi_shard_route', _p(toffs), T, _p(ids), _idx_bits(ids), B, n_ranks, _p(send), _p(err), _stream())
+
+
+def fm_partial_fwd(table, local_rows, recv, n_ranks, B, T, partial, rows_out, entry_sample, n_out, err=None):
+    if recv.numel() < n_ranks * shard_block_ints(B, T) or min(rows_out.numel(), entry_sample.numel()) < n_ranks * B * T \
+            or partial.numel() < n_ranks * B * (table.dim + 2):
+        raise MiError("fm_partial_fwd: buffer too small")
+    _lib.call('mi_fm_partial_fwd', table.ref(), local_rows, _p(recv), n_ranks, B, T, _p(partial), _p(rows_out),
+              _p(entry_sample), _p(n_out), _p(err), _stream())
+
+
+def fm_combine(partials, n_ranks, B, dim, dense, wd, bias, labels, gscale, X, logit=None):
+    n_dense = dense.shape[1] if dense is not None else 0
+    if X.shape[0] < B or partials.numel() < n_ranks * B * (dim + 2):
+        raise MiError("fm_combine: buffer too small")
+    _lib.call('mi_fm_combine', _p(partials), n_ranks, B, dim, _p(dense), n_dense, _p(wd), _p(bias), _p(labels),
+              gscale, _p(logit), _p(X), X.shape[1], _stream())
+
+
+def fm_bwd_apply_rows(plan, table, X, entry_sample, opt, lr, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None):
+    if entry_sample.numel() < plan.n_entries:
+        raise MiError("fm_bwd_apply_rows: entry_sample shorter than the plan")
+    _lib.call('mi_fm_bwd_apply_rows', plan.ref(), table.ref(), _p(X), X.shape[1], _p(entry_sample), opt, lr,
+              _p(lr_dev), beta1, beta2, eps, _stream())
+
+
+def fm_dense_step_rows(X, dim, n_dense, dp, dm, dv, lr_t, beta1, beta2, eps, loss_out, lr_dev=None):
+    _lib.call('mi_fm_dense_step_rows', _p(X), X.shape[1], dim, n_dense, X.shape[0], _p(dp), _p(dm), _p(dv), lr_t,
+              _p(lr_dev), beta1, beta2, eps, _p(loss_out), _stream())

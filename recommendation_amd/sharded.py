@@ -1,0 +1,253 @@
+"""Row-wise sharded embedding tables across the GPUs of one node (one process per GPU).
+
+The reference distributes with TensorFlow's asynchronous parameter server: 2 workers + 1 ps,
+every variable read and Adam apply a gRPC hop (recommendation/code/model_trainer.py:124-136,
+recommendation/train_job.py:41-42).  That scheme is not reproduced.  Here
+
+* the rows of all tables are dealt round-robin over the N ranks (global row r = offset[t] + id
+  lives on rank r % N as local row r / N), so any id distribution loads the ranks evenly;
+* the small dense side (dense-feature weights, bias) is replicated;
+* a step is synchronous: every rank contributes its own batch of B samples, the loss is the mean
+  over the N*B samples, and after the step all replicas agree bit for bit.
+
+A step has THREE collectives (RCCL over xGMI through torch.distributed, backend "nccl"), all of
+fixed size, so nothing on the host waits for the device before they are issued:
+
+  A. all-to-all  [N][B+1+B*T] int32   requester -> owner: per-sample offsets + the local rows
+  B. all-to-all  [N][B][D+2] fp32     owner -> requester: per SAMPLE sum v, sum |v|^2, sum w1
+                                      (not per (sample, field))
+  C. all-gather  [B][D+2+nd] fp32     every sample's S, dL/dlogit, loss row and dense features
+
+After C every owner has what its sparse backward needs and every replica computes the dense-side
+gradients of all N*B samples itself, in the same order, so there is no all-reduce.  The sparse
+backward and the fused optimizer run entirely on the owner: no gradient row crosses the fabric.
+Local compute goes through a small backend object so that the exchange logic can be exercised
+with gloo on CPU (tests plug in a numpy stand-in); the product backend is ``HipBackend`` and there
+is no other.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .fm import _OPT
+
+
+def local_row_count(total_rows, rank, world):
+    return (total_rows - rank + world - 1) // world
+
+
+class HipBackend(object):
+    """Local compute of one rank: every method is one or two C-ABI calls."""
+
+    def __init__(self, rows_per_table, dim, n_dense, device, opt, rank, world):
+        self.device = torch.device(device)
+        self.T, self.dim, self.n_dense, self.opt = len(rows_per_table), dim, n_dense, opt
+        self.rank, self.world = rank, world
+        self.total_rows = int(sum(rows_per_table))
+        self.local_rows = local_row_count(self.total_rows, rank, world)
+        self.toffs = ops.table_offsets(rows_per_table, self.device)
+        self.table = ops.FmRecords(max(self.local_rows, 1), dim, _OPT[opt], self.device)
+        self.local_toffs = ops.table_offsets([max(self.local_rows, 1)], self.device)
+        self.err = ops.new_error_word(self.device)
+        self.plan = None
+        self.n_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.n_ready = torch.cuda.Event()
+
+    # parameters ------------------------------------------------------------------------------
+    def init_rows(self, V, w1):
+        """V [local_rows, dim], w1 [local_rows] for this shard."""
+        self.table.rec[:self.local_rows, :self.dim] = V.to(self.device)
+        self.table.rec[:self.local_rows, self.table.off_w1] = w1.to(self.device)
+
+    def rows(self):
+        return (self.table.rec[:self.local_rows, :self.dim], self.table.rec[:self.local_rows, self.table.off_w1])
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    # step pieces -----------------------------------------------------------------------------
+    def route(self, ids, send):
+        ops.shard_route(self.toffs, ids, self.world, send, self.err)
+
+    def partial_fwd(self, recv, B, partial, rows_out, entry_sample, n_dev):
+        ops.fm_partial_fwd(self.table, self.local_rows, recv, self.world, B, self.T, partial, rows_out,
+                           entry_sample, n_dev, self.err)
+        # the number of received rows travels to the host behind the kernel; it is only needed
+        # when the backward is enqueued, two collectives later
+        self.n_host.copy_(n_dev, non_blocking=True)
+        self.n_ready.record()
+
+    def received(self):
+        self.n_ready.synchronize()
+        return int(self.n_host[0])
+
+    def combine(self, partials, B, dense, wd, bias, labels, gscale, X):
+        ops.fm_combine(partials, self.world, B, self.dim, dense, wd, bias, labels, gscale, X)
+
+    def dense_step(self, X_all, dp, dm, dv, lr, beta1, beta2, eps, sched, loss):
+        ops.adam_schedule_step(sched, lr, beta1, beta2)
+        ops.fm_dense_step_rows(X_all, self.dim, self.n_dense, dp, dm, dv, 0.0, beta1, beta2, eps, loss,
+                               lr_dev=sched)
+
+    def owner_backward(self, rows, n_recv, entry_sample, X_all, lr, beta1, beta2, eps, sched):
+        if n_recv == 0:
+            return
+        if self.plan is None or self.plan.indices.data_ptr() != rows.data_ptr():
+            self.plan = ops.SortedPlan(self.local_toffs, 1, max(self.local_rows, 1), rows, bag_len=1, runs=False)
+        self.plan.prepare_prefix(n_recv)
+        adam = self.opt == 'adam_tf'
+        ops.fm_bwd_apply_rows(self.plan, self.table, X_all, entry_sample, _OPT[self.opt], lr, beta1, beta2, eps,
+                              lr_dev=sched if adam else None)
+
+    def check(self):
+        ops.check_error_word(self.err, "sharded FM ids")
+
+
+class TorchComm(object):
+    """The collectives of a step, on torch.distributed (RCCL when the backend is nccl)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_to_all(self, out, inp):
+        dist.all_to_all_single(out, inp, group=self.group)
+
+    def all_gather(self, out, inp):
+        dist.all_gather_into_tensor(out, inp, group=self.group)
+
+
+class ShardedFactorizationMachine(object):
+    def __init__(self, rows_per_table, dim, n_dense, device, opt='adam_tf', lr=1e-3, beta1=0.9, beta2=0.999,
+                 eps=1e-8, seed=0, init_scale=0.05, comm=None, backend=None, rank=None, world=None):
+        self.comm = comm if comm is not None else (TorchComm() if rank is None else None)
+        self.rank = self.comm.rank if rank is None else rank
+        self.world = self.comm.world if world is None else world
+        self.rows_per_table = [int(r) for r in rows_per_table]
+        self.T, self.dim, self.n_dense = len(rows_per_table), int(dim), int(n_dense)
+        self.opt, self.lr, self.beta1, self.beta2, self.eps = opt, lr, beta1, beta2, eps
+        self.total_rows = sum(self.rows_per_table)
+        self.be = backend if backend is not None else HipBackend(self.rows_per_table, self.dim, self.n_dense, device,
+                                                                 opt, self.rank, self.world)
+        self.device = self.be.device
+        f32 = torch.float32
+        # replicated dense side; same seed on every rank -> identical replicas
+        gen = torch.Generator(device='cpu')
+        gen.manual_seed(seed)
+        dp = torch.zeros(self.n_dense + 1, dtype=f32)
+        dp[:self.n_dense] = torch.randn(self.n_dense, generator=gen, dtype=f32) * init_scale
+        self.dp = dp.to(self.device)
+        self.dm, self.dv = torch.zeros_like(self.dp), torch.zeros_like(self.dp)
+        self.sched = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=f32, device=self.device)
+        # this rank's rows: every rank seeds its own generator
+        if backend is None:
+            g = torch.Generator(device=self.device)
+            g.manual_seed(seed * 1000003 + self.rank)
+            n = self.be.local_rows
+            chunk = 1 << 22
+            for lo in range(0, n, chunk):
+                hi = min(lo + chunk, n)
+                self.be.table.rec[lo:hi, :self.dim + 1] = torch.randn((hi - lo, self.dim + 1), generator=g,
+                                                                      dtype=f32, device=self.device) * init_scale
+        self.err = getattr(self.be, 'err', None)
+        self._B = None
+        self.loss = None
+
+    # -- parameters ---------------------------------------------------------------------------
+    @property
+    def wd(self):
+        return self.dp[:self.n_dense]
+
+    @property
+    def bias(self):
+        return self.dp[self.n_dense:]
+
+    def load_state(self, st):
+        """Take this rank's rows (global rows rank, rank+N, ...) from a full-table state."""
+        V = torch.from_numpy(st.V[self.rank::self.world].copy())
+        w1 = torch.from_numpy(st.w1[self.rank::self.world].copy())
+        self.be.init_rows(V, w1)
+        self.dp[:self.n_dense] = torch.from_numpy(st.wd).to(self.device)
+        self.dp[self.n_dense] = float(st.bias)
+
+    # -- buffers ------------------------------------------------------------------------------
+    def _buffers(self, B):
+        if self._B == B:
+            return
+        N, D, be = self.world, self.dim, self.be
+        i32, f32 = torch.int32, torch.float32
+        blk = ops.shard_block_ints(B, self.T)
+        self.ld = ops.shard_row_floats(D, self.n_dense)
+        self.send, self.recv = be.zeros((N, blk), i32), be.zeros((N, blk), i32)
+        cap = N * B * self.T                       # an owner can at most receive every entry of every rank
+        self.rows_in, self.entry_sample = be.zeros((cap,), i32), be.zeros((cap,), i32)
+        self.n_dev = be.zeros((1,), i32)
+        self.partial, self.partials_in = be.zeros((N, B, D + 2), f32), be.zeros((N, B, D + 2), f32)
+        self.X, self.X_all = be.zeros((B, self.ld), f32), be.zeros((N * B, self.ld), f32)
+        self.loss = be.zeros((1,), f32)
+        self._B = B
+
+    # -- the phases of a step (public so that a test can drive several ranks in lockstep) -------
+    def phase_route(self, ids):
+        """ids [B][T] -> self.send [N][blk] (exchange A: all-to-all into self.recv)."""
+        self._buffers(ids.shape[0])
+        self.be.route(ids, self.send)
+        return self.send
+
+    def phase_owner_forward(self):
+        """self.recv -> self.partial [N][B][D+2] (exchange B: all-to-all into self.partials_in)."""
+        self.be.partial_fwd(self.recv, self._B, self.partial, self.rows_in, self.entry_sample, self.n_dev)
+        return self.partial
+
+    def phase_combine(self, dense, labels):
+        """self.partials_in -> self.X [B][ld] (exchange C: all-gather into self.X_all)."""
+        B = self._B
+        self.be.combine(self.partials_in, B, dense if self.n_dense else None, self.wd if self.n_dense else None,
+                        self.bias, labels, 1.0 / (B * self.world), self.X)
+        return self.X
+
+    def phase_update(self):
+        """Dense step on every replica, sparse backward + optimizer on the owner."""
+        self.be.dense_step(self.X_all, self.dp, self.dm, self.dv, self.lr, self.beta1, self.beta2, self.eps,
+                           self.sched, self.loss)
+        self.be.owner_backward(self.rows_in, self.be.received(), self.entry_sample, self.X_all, self.lr, self.beta1,
+                               self.beta2, self.eps, self.sched)
+
+    # -- one step over torch.distributed --------------------------------------------------------
+    def train_step(self, ids, dense, labels, check_ids=False):
+        c = self.comm
+        self.phase_route(ids)
+        c.all_to_all(self.recv, self.send)                 # A
+        self.phase_owner_forward()
+        c.all_to_all(self.partials_in, self.partial)       # B
+        self.phase_combine(dense, labels)
+        c.all_gather(self.X_all, self.X)                   # C
+        self.phase_update()
+        if check_ids and hasattr(self.be, 'check'):
+            self.be.check()
+        return self.loss
+
+
+def lockstep_train_step(models, batches):
+    """Drive the models of ALL ranks in one process, phase by phase, doing each exchange with plain
+    tensor copies.  Same phases and buffers as ``train_step`` over torch.distributed; used to check
+    the protocol and the kernels on a single GPU."""
+    B = batches[0][0].shape[0]
+    for m, (ids, _, _) in zip(models, batches):
+        m.phase_route(ids)
+    for r, m in enumerate(models):                       # exchange A
+        for s, ms in enumerate(models):
+            m.recv[s].copy_(ms.send[r])
+        m.phase_owner_forward()
+    for s, ms in enumerate(models):                      # exchange B
+        for r, m in enumerate(models):
+            ms.partials_in[r].copy_(m.partial[s])
+    for m, (_, dense, labels) in zip(models, batches):
+        m.phase_combine(dense, labels)
+    for m in models:                                     # exchange C
+        for s, ms in enumerate(models):
+            m.X_all[s * B:(s + 1) * B].copy_(ms.X)
+    for m in models:
+        m.phase_update()
+    return models[0].loss
