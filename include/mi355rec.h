@@ -337,6 +337,49 @@ int mi_fm_dense_step_rows(const float* X, int ld, int dim, int n_dense, int64_t 
                           float* dm, float* dv, float lr_t, const float* lr_dev, float beta1,
                           float beta2, float eps, float* loss_out, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * bf16 MFMA contractions (DCN-v2 cross layers and MLP, DIN activation unit).  Not in the
+ * reference, whose dense layers are fp32 tf.layers.dense on a 5,910-parameter network
+ * (r_model.py:53-57); these are the dense contractions of the interaction models the benchmark
+ * definition adds, and the only work put on the matrix cores.  bf16 operands, fp32 accumulate;
+ * agreement with an fp32 evaluation is within 1e-2.
+ * ---------------------------------------------------------------------------------- */
+#define MI_EPI_SLAB 0      /* out: fp32 [k_splits][M][ld_out] partial products (summed by mi_slab_adam) */
+#define MI_EPI_BIAS_ACT 1  /* out (bf16) = act(C + bias[n]); flags & MI_EPI_RELU */
+#define MI_EPI_CROSS_FWD 2 /* u = C + bias -> out1 (bf16, optional); out (bf16) = in0 * u + in1 */
+#define MI_EPI_MASK 3      /* out (bf16) = C where in0 > 0 else 0 (in0 NULL: plain store) */
+#define MI_EPI_CROSS_BWD 4 /* v = C + in1 (optional) -> out (bf16, optional); with out1: out1 = v*in0,
+                              facc += v*in2; without: facc += v.  MI_EPI_INIT: facc starts at 0 */
+#define MI_EPI_RELU 1
+#define MI_EPI_INIT 2
+
+typedef struct mi_gemm_epilogue {
+  int mode, flags;
+  void* out;
+  int64_t ld_out;
+  const float* bias;
+  const void* in0;
+  int64_t ld_in0;
+  const void* in1;
+  int64_t ld_in1;
+  const void* in2;
+  int64_t ld_in2;
+  void* out1;
+  int64_t ld_out1;
+  float* facc;
+  int64_t ld_facc;
+} mi_gemm_epilogue;
+
+/* C[m][n] = sum_k A(m,k)*B(n,k), followed by the epilogue.  An operand is stored either
+ * reduction-contiguous (A[m*lda + k], B[n*ldb + k]) or, with its *_reduction_major flag set,
+ * reduction-major (A[k*lda + m], B[k*ldb + n]) - the backward contractions need the latter and
+ * get it without any transposed copy in HBM.  M, N multiples of 8, K a multiple of 64;
+ * k_splits > 1 (MI_EPI_SLAB only) cuts K into that many slices, each a whole number of 64-deep
+ * tiles. */
+int mi_gemm_bf16(int a_reduction_major, int b_reduction_major, int64_t M, int64_t N, int64_t K,
+                 const void* A, int64_t lda, const void* B, int64_t ldb, int k_splits,
+                 const mi_gemm_epilogue* epi, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,14 @@ class FmTable(Structure):
                 ('off_vs1', c_int), ('off_ws0', c_int), ('off_ws1', c_int)]
 
 
+class GemmEpilogue(Structure):
+    """struct mi_gemm_epilogue"""
+    _fields_ = [('mode', c_int), ('flags', c_int), ('out', c_void_p), ('ld_out', c_int64), ('bias', c_void_p),
+                ('in0', c_void_p), ('ld_in0', c_int64), ('in1', c_void_p), ('ld_in1', c_int64), ('in2', c_void_p),
+                ('ld_in2', c_int64), ('out1', c_void_p), ('ld_out1', c_int64), ('facc', c_void_p),
+                ('ld_facc', c_int64)]
+
+
 P = c_void_p
 _SIGNATURES = {
     'mi_version': (c_char_p, []),
@@ -72,6 +80,8 @@ _SIGNATURES = {
     'mi_fm_bwd_dense': (c_int, [P, P, c_int, c_int64, P, P]),
     'mi_fm_dense_step': (c_int, [P, P, c_int, c_int64, P, P, P, P, c_float, P, c_float, c_float, c_float, P, P]),
     'mi_adam_schedule_step': (c_int, [P, c_float, c_float, c_float, P]),
+    'mi_gemm_bf16': (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, c_int,
+                             POINTER(GemmEpilogue), P]),
     'mi_shard_block_ints': (c_int64, [c_int64, c_int]),
     'mi_shard_route': (c_int, [P, c_int, P, c_int, c_int64, c_int, P, P, P]),
     'mi_fm_partial_fwd': (c_int, [POINTER(FmTable), c_int64, P, c_int, c_int64, c_int, P, P, P, P, P, P]),

@@ -1,0 +1,322 @@
+// bf16 MFMA contraction for the dense parts of the feature-interaction models (DCN-v2 cross
+// layers and MLP, DIN activation unit).  The reference's dense layers are tf.layers.dense in
+// fp32 on a 5,910-parameter network (recommendation/code/r_model.py:53-57); the contractions
+// here are the ones the larger interaction models add, and the only work in this library that
+// is put on the matrix cores.
+//
+//   C[m][n] = sum_k A(m,k) * B(n,k)        fp32 accumulate, bf16 operands
+//
+// Either operand may be stored "reduction-contiguous" (row m holds its k values back to back:
+// activations X[M][K], weights W[N][K]) or "reduction-major" (row k holds all m: what the
+// backward contractions need - dX = dY*W sums over W's ROW index, dW = dY^T*X sums over the
+// batch).  Reduction-major tiles are staged as they lie in memory and read from LDS with the
+// transposing read (ds_read_b64_tr_b16), so no transposed copy of any activation or weight is
+// ever written to HBM.
+//
+// Tile 128x128x64, 4 waves as 2x2, each wave 4x4 fragments of mfma_f32_16x16x32_bf16,
+// register-staged global loads one tile ahead, two LDS buffers, one barrier per K tile.
+#include "common.h"
+
+namespace {
+
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s4v* lds_s4v_ptr;
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per buffer
+
+// LDS image of a reduction-contiguous tile: [128 rows][64 k] = 128-byte rows of eight 16-byte
+// chunks; chunk position XORed with the row so that the 16 rows of a fragment spread over banks.
+__device__ __forceinline__ int row_img(int r, int ch) { return r * 128 + ((ch ^ (r & 7)) << 4); }
+// LDS image of a reduction-major tile: [64 k][128 rows] = 256-byte rows of sixteen chunks, with
+// the XOR under which both the transposing reads of a 16x16x32 operand are conflict-free.
+__device__ __forceinline__ int tr_img(int kr, int ch) {
+  return kr * 256 + ((ch ^ (((kr & 3) << 2) | ((kr >> 2) & 3))) << 4);
+}
+
+// Staging: each thread moves four 16-byte chunks per operand and K tile, global -> registers ->
+// LDS.  Chunk i of thread t is chunk c = t + 256*i of the tile.
+// rows [row0, row0+128) x k [k0, k0+64) of an operand with R rows in total
+template <bool TR>
+__device__ __forceinline__ uint4 load_chunk(const unsigned short* __restrict__ P, int64_t ld, int64_t row0, int64_t R,
+                                            int64_t k0, int i) {
+  const int c = threadIdx.x + NTHREADS * i;
+  if constexpr (!TR) {
+    const int r = c >> 3, ch = c & 7;
+    int64_t rr = row0 + r;
+    rr = rr < R ? rr : R - 1;  // out-of-range rows read a valid row; their results are never stored
+    return *reinterpret_cast<const uint4*>(P + rr * ld + k0 + ch * 8);
+  } else {
+    const int kr = c >> 4, ch = c & 15;
+    int64_t m = row0 + ch * 8;
+    m = m <= R - 8 ? m : R - 8;
+    return *reinterpret_cast<const uint4*>(P + (k0 + kr) * ld + m);
+  }
+}
+template <bool TR>
+__device__ __forceinline__ void store_chunk(char* lds, int i, uint4 v) {
+  const int c = threadIdx.x + NTHREADS * i;
+  const int off = TR ? tr_img(c >> 4, c & 15) : row_img(c >> 3, c & 7);
+  *reinterpret_cast<uint4*>(lds + off) = v;
+}
+
+// fragment f (16 rows of the tile), k-step kk (32 of the tile's 64 k): lane l gets row l&15,
+// k = 8*(l>>4) + 0..7
+template <bool TR>
+__device__ __forceinline__ s8v read_frag(const char* lds, int f, int kk, int lane) {
+  if constexpr (!TR) {
+    const int r = f * 16 + (lane & 15), ch = kk * 4 + (lane >> 4);
+    return *reinterpret_cast<const s8v*>(lds + row_img(r, ch));
+  } else {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int c0 = f * 2 + (p >> 1), r0 = kk * 32 + 8 * g + q;
+    const s4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr) (lds + tr_img(r0, c0) + 8 * (p & 1)));
+    const s4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr) (lds + tr_img(r0 + 4, c0) + 8 * (p & 1)));
+    return s8v{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  }
+}
+
+struct GemmArgs {
+  const unsigned short* A;
+  const unsigned short* B;
+  int64_t lda, ldb, M, N, K, k_per_split;
+  int tiles_n;
+  mi_gemm_epilogue e;
+};
+
+__device__ __forceinline__ float4 ld_bf4(const void* p, int64_t ld, int64_t m, int64_t n) {
+  const ushort4 u = *reinterpret_cast<const ushort4*>(reinterpret_cast<const unsigned short*>(p) + m * ld + n);
+  return make_float4(mi_bf2f(u.x), mi_bf2f(u.y), mi_bf2f(u.z), mi_bf2f(u.w));
+}
+__device__ __forceinline__ void st_bf4(void* p, int64_t ld, int64_t m, int64_t n, float4 v) {
+  ushort4 u;
+  u.x = mi_f2bf(v.x); u.y = mi_f2bf(v.y); u.z = mi_f2bf(v.z); u.w = mi_f2bf(v.w);
+  *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(p) + m * ld + n) = u;
+}
+
+// what happens to C[m][n..n+3] (n % 4 == 0, all four in range)
+__device__ __forceinline__ void epilogue(const mi_gemm_epilogue& e, int64_t M, int64_t N, int z, int64_t m, int64_t n,
+                                         float4 v) {
+  switch (e.mode) {
+    case MI_EPI_SLAB: {  // fp32 partial of K-slice z
+      float* o = reinterpret_cast<float*>(e.out) + ((int64_t) z * M + m) * e.ld_out + n;
+      *reinterpret_cast<float4*>(o) = v;
+      break;
+    }
+    case MI_EPI_BIAS_ACT: {  // out = act(acc + bias)
+      if (e.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      if (e.flags & MI_EPI_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      st_bf4(e.out, e.ld_out, m, n, v);
+      break;
+    }
+    case MI_EPI_CROSS_FWD: {  // u = acc + bias -> out1;  out = in0 (x0) * u + in1 (x_l)
+      const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      if (e.out1) st_bf4(e.out1, e.ld_out1, m, n, v);
+      const float4 x0 = ld_bf4(e.in0, e.ld_in0, m, n), xl = ld_bf4(e.in1, e.ld_in1, m, n);
+      st_bf4(e.out, e.ld_out, m, n,
+             make_float4(fmaf(x0.x, v.x, xl.x), fmaf(x0.y, v.y, xl.y), fmaf(x0.z, v.z, xl.z), fmaf(x0.w, v.w, xl.w)));
+      break;
+    }
+    case MI_EPI_MASK: {  // out = acc where in0 > 0 else 0 (ReLU backward of the layer that produced in0)
+      if (e.in0) {
+        const float4 h = ld_bf4(e.in0, e.ld_in0, m, n);
+        v.x = h.x > 0.f ? v.x : 0.f; v.y = h.y > 0.f ? v.y : 0.f;
+        v.z = h.z > 0.f ? v.z : 0.f; v.w = h.w > 0.f ? v.w : 0.f;
+      }
+      st_bf4(e.out, e.ld_out, m, n, v);
+      break;
+    }
+    case MI_EPI_CROSS_BWD: {
+      // v = acc + in1 (dx_{l+1}, optional) is dx_l -> out.  With out1: out1 = v * in0 (x0) is du_{l-1}
+      // and facc (d x0, fp32) gains v * in2 (u_{l-1}); without out1 (l == 0) facc gains v itself.
+      if (e.in1) {
+        const float4 r = ld_bf4(e.in1, e.ld_in1, m, n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      if (e.out) st_bf4(e.out, e.ld_out, m, n, v);
+      float* fa = e.facc + m * e.ld_facc + n;
+      float4 acc = (e.flags & MI_EPI_INIT) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(fa);
+      if (e.out1) {
+        const float4 x0 = ld_bf4(e.in0, e.ld_in0, m, n), u = ld_bf4(e.in2, e.ld_in2, m, n);
+        st_bf4(e.out1, e.ld_out1, m, n, make_float4(v.x * x0.x, v.y * x0.y, v.z * x0.z, v.w * x0.w));
+        acc.x = fmaf(v.x, u.x, acc.x); acc.y = fmaf(v.y, u.y, acc.y);
+        acc.z = fmaf(v.z, u.z, acc.z); acc.w = fmaf(v.w, u.w, acc.w);
+      } else {
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<float4*>(fa) = acc;
+      break;
+    }
+    default:
+      break;
+  }
+}
+
+template <bool A_TR, bool B_TR>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const As = smem;                   // two buffers of TILE_BYTES
+  char* const Bs = smem + 2 * TILE_BYTES;  // two buffers of TILE_BYTES
+  // consecutive workgroup ids go round-robin over the 8 XCDs; renumber so that each XCD (its own
+  // L2) works on consecutive tiles, i.e. the n-tiles that share one A row block
+  const int nb = gridDim.x, id = blockIdx.x, xcd = id & 7, q = nb >> 3, r = nb & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  const int tn = lid % a.tiles_n, tm = lid / a.tiles_n;
+  const int64_t m0 = (int64_t) tm * BM, n0 = (int64_t) tn * BN;
+  const int z = blockIdx.y;
+  const int64_t kbeg = (int64_t) z * a.k_per_split;
+  const int64_t kend = kbeg + a.k_per_split < a.K ? kbeg + a.k_per_split : a.K;
+  const int ktiles = (int) ((kend - kbeg) / BK);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1;
+
+  f4v acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+
+#define LOAD_TILE(k0_)                                         \
+  a0 = load_chunk<A_TR>(a.A, a.lda, m0, a.M, (k0_), 0);        \
+  a1 = load_chunk<A_TR>(a.A, a.lda, m0, a.M, (k0_), 1);        \
+  a2 = load_chunk<A_TR>(a.A, a.lda, m0, a.M, (k0_), 2);        \
+  a3 = load_chunk<A_TR>(a.A, a.lda, m0, a.M, (k0_), 3);        \
+  b0 = load_chunk<B_TR>(a.B, a.ldb, n0, a.N, (k0_), 0);        \
+  b1 = load_chunk<B_TR>(a.B, a.ldb, n0, a.N, (k0_), 1);        \
+  b2 = load_chunk<B_TR>(a.B, a.ldb, n0, a.N, (k0_), 2);        \
+  b3 = load_chunk<B_TR>(a.B, a.ldb, n0, a.N, (k0_), 3);
+#define STORE_TILE(buf_)                                       \
+  store_chunk<A_TR>(As + (buf_) * TILE_BYTES, 0, a0);          \
+  store_chunk<A_TR>(As + (buf_) * TILE_BYTES, 1, a1);          \
+  store_chunk<A_TR>(As + (buf_) * TILE_BYTES, 2, a2);          \
+  store_chunk<A_TR>(As + (buf_) * TILE_BYTES, 3, a3);          \
+  store_chunk<B_TR>(Bs + (buf_) * TILE_BYTES, 0, b0);          \
+  store_chunk<B_TR>(Bs + (buf_) * TILE_BYTES, 1, b1);          \
+  store_chunk<B_TR>(Bs + (buf_) * TILE_BYTES, 2, b2);          \
+  store_chunk<B_TR>(Bs + (buf_) * TILE_BYTES, 3, b3);
+  uint4 a0, a1, a2, a3, b0, b1, b2, b3;
+  LOAD_TILE(kbeg)
+  STORE_TILE(0)
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < ktiles;
+    // always issued (the last iteration re-reads its own tile) so that the staging registers are
+    // written unconditionally and stay registers
+    const int64_t knext = kbeg + (int64_t) (more ? kt + 1 : kt) * BK;
+    LOAD_TILE(knext)
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the MFMAs: they fly while the tile is computed
+    const char* Ac = As + cur * TILE_BYTES;
+    const char* Bc = Bs + cur * TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      s8v fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_TR>(Ac, wr * 4 + i, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_TR>(Bc, wc * 4 + j, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // first operand indexes the result's rows (kept in registers): n; second its columns (lanes): m
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, fb[j]),
+                                                              __builtin_bit_cast(bf8v, fa[i]), acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      STORE_TILE(cur ^ 1)
+    }
+    __syncthreads();
+  }
+#undef LOAD_TILE
+#undef STORE_TILE
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wr * 64 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+      if (m < a.M && n < a.N) epilogue(a.e, a.M, a.N, z, m, n, make_float4(acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w));
+    }
+  }
+}
+
+bool al16p(const void* p) { return ((uintptr_t) p & 15) == 0; }
+bool al8p(const void* p) { return ((uintptr_t) p & 7) == 0; }
+
+}  // namespace
+
+extern "C" int mi_gemm_bf16(int a_reduction_major, int b_reduction_major, int64_t M, int64_t N, int64_t K,
+                            const void* A, int64_t lda, const void* B, int64_t ldb, int k_splits,
+                            const mi_gemm_epilogue* epi, void* stream) {
+  const char* who = "mi_gemm_bf16";
+  MI_REQUIRE(A && B && epi, "%s: null pointer", who);
+  MI_REQUIRE(M >= 8 && N >= 8 && K >= BK && M % 8 == 0 && N % 8 == 0 && K % BK == 0,
+             "%s: M, N must be multiples of 8 and K of %d (got %lld, %lld, %lld)", who, BK, (long long) M, (long long) N,
+             (long long) K);
+  MI_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && al16p(A) && al16p(B), "%s: operands need 16-byte aligned rows", who);
+  MI_REQUIRE(lda >= (a_reduction_major ? M : K) && ldb >= (b_reduction_major ? N : K), "%s: leading dimension too small", who);
+  MI_REQUIRE(k_splits >= 1 && k_splits <= 4096, "%s: k_splits %d", who, k_splits);
+  MI_REQUIRE(epi->mode == MI_EPI_SLAB || k_splits == 1, "%s: only MI_EPI_SLAB takes a split reduction", who);
+  const mi_gemm_epilogue& e = *epi;
+  auto bf_ok = [](const void* p, int64_t ld) { return !p || (al8p(p) && ld % 4 == 0); };
+  switch (e.mode) {
+    case MI_EPI_SLAB:
+      MI_REQUIRE(e.out && al16p(e.out) && e.ld_out % 4 == 0 && e.ld_out >= N, "%s: slab output", who);
+      break;
+    case MI_EPI_BIAS_ACT:
+      MI_REQUIRE(e.out && bf_ok(e.out, e.ld_out) && (!e.bias || al16p(e.bias)), "%s: bias/activation epilogue", who);
+      break;
+    case MI_EPI_CROSS_FWD:
+      MI_REQUIRE(e.out && e.bias && e.in0 && e.in1 && al16p(e.bias) && bf_ok(e.out, e.ld_out) && bf_ok(e.out1, e.ld_out1) &&
+                     bf_ok(e.in0, e.ld_in0) && bf_ok(e.in1, e.ld_in1),
+                 "%s: cross-forward epilogue", who);
+      break;
+    case MI_EPI_MASK:
+      MI_REQUIRE(e.out && bf_ok(e.out, e.ld_out) && bf_ok(e.in0, e.ld_in0), "%s: mask epilogue", who);
+      break;
+    case MI_EPI_CROSS_BWD:
+      MI_REQUIRE(e.facc && al16p(e.facc) && e.ld_facc % 4 == 0 && bf_ok(e.out, e.ld_out) && bf_ok(e.in1, e.ld_in1) &&
+                     (!e.out1 || (e.in0 && e.in2 && bf_ok(e.out1, e.ld_out1) && bf_ok(e.in0, e.ld_in0) &&
+                                  bf_ok(e.in2, e.ld_in2))),
+                 "%s: cross-backward epilogue", who);
+      break;
+    default:
+      mi_set_error("%s: unknown epilogue mode %d", who, e.mode);
+      return MI_ERR_INVALID_ARG;
+  }
+  int64_t k_per = mi_cdiv(mi_cdiv(K, k_splits), BK) * BK;
+  const int splits = (int) mi_cdiv(K, k_per);
+  MI_REQUIRE(splits == k_splits, "%s: K=%lld does not divide into %d slices of whole %d-deep tiles (would be %d)", who,
+             (long long) K, k_splits, BK, splits);
+  GemmArgs g;
+  g.A = (const unsigned short*) A;
+  g.B = (const unsigned short*) B;
+  g.lda = lda; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.k_per_split = k_per;
+  g.tiles_n = (int) mi_cdiv(N, BN);
+  g.e = e;
+  const int64_t tiles = mi_cdiv(M, BM) * g.tiles_n;
+  MI_REQUIRE(tiles < ((int64_t) 1 << 31), "%s: too many tiles", who);
+  const dim3 grid((unsigned) tiles, (unsigned) splits), block(NTHREADS);
+  const size_t lds = 4 * TILE_BYTES;
+  hipStream_t s = (hipStream_t) stream;
+  if (!a_reduction_major && !b_reduction_major)
+    hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, lds, s, g);
+  else if (!a_reduction_major && b_reduction_major)
+    hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, lds, s, g);
+  else if (a_reduction_major && b_reduction_major)
+    hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, lds, s, g);
+  else
+    hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, lds, s, g);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}

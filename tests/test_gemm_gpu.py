@@ -1,0 +1,125 @@
+"""bf16 MFMA contraction against torch fp32 matmul of the same bf16-rounded operands.
+With small-integer operands every product and sum is exact in fp32, so those cases are bit-exact
+and catch any wrong lane map / transposed tile; random operands are held to 1e-2 (bf16 outputs)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ints(shape, dev, seed, lo=-3, hi=4):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).to(torch.bfloat16).to(dev)
+
+
+def _operands(M, N, K, a_rm, b_rm, dev, seed, ints=True):
+    if ints:
+        a, b = _ints((M, K), dev, seed), _ints((N, K), dev, seed + 1)
+    else:
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        a = (torch.rand((M, K), generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+        b = (torch.rand((N, K), generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    A = a.t().contiguous() if a_rm else a
+    B = b.t().contiguous() if b_rm else b
+    return a, b, A, B
+
+
+@pytest.mark.parametrize("a_rm,b_rm", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 448, 448), (1000, 72, 192), (8, 8, 64), (384, 1024, 512)])
+def test_slab_exact_on_integers(dev, a_rm, b_rm, M, N, K):
+    from recommendation_amd import ops
+    a, b, A, B = _operands(M, N, K, a_rm, b_rm, dev, seed=M + N + K)
+    out = torch.full((1, M, N), float('nan'), dtype=torch.float32, device=dev)
+    ops.gemm_bf16(A, B, ops.MI_EPI_SLAB, a_rm=a_rm, b_rm=b_rm, out=out)
+    want = a.float() @ b.float().t()
+    assert torch.equal(out[0], want)
+
+
+def test_identity_times_asymmetric(dev):
+    """A = I picks out B's rows: a swapped row/column map in the result cannot hide."""
+    from recommendation_amd import ops
+    n = 128
+    A = torch.eye(n, dtype=torch.bfloat16, device=dev)
+    Bm = (torch.arange(n, device=dev)[:, None] * 2 + torch.arange(n, device=dev)[None, :] % 7).to(torch.bfloat16)
+    out = torch.empty((1, n, n), dtype=torch.float32, device=dev)
+    ops.gemm_bf16(A, Bm, ops.MI_EPI_SLAB, out=out)           # C = I * Bm^T
+    assert torch.equal(out[0], Bm.float().t())
+
+
+@pytest.mark.parametrize("splits", [2, 4, 16])
+def test_split_k_slabs_sum_to_the_product(dev, splits):
+    from recommendation_amd import ops
+    M, N, K = 448, 448, 64 * 16
+    a, b, A, B = _operands(M, N, K, True, True, dev, seed=9)
+    out = torch.zeros((splits, M, N), dtype=torch.float32, device=dev)
+    ops.gemm_bf16(A, B, ops.MI_EPI_SLAB, a_rm=True, b_rm=True, k_splits=splits, out=out)
+    assert torch.equal(out.sum(0), a.float() @ b.float().t())
+    per = K // splits
+    assert torch.equal(out[1], a[:, per:2 * per].float() @ b[:, per:2 * per].float().t())
+
+
+def test_bias_relu_epilogue(dev):
+    from recommendation_amd import ops
+    M, N, K = 512, 1024, 448
+    a, b, A, B = _operands(M, N, K, False, False, dev, seed=3, ints=False)
+    bias = torch.linspace(-1, 1, N, device=dev)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm_bf16(A, B, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=out, bias=bias)
+    want = torch.relu(a.float() @ b.float().t() + bias)
+    err = (out.float() - want).abs().max() / want.abs().max()
+    assert err <= 1e-2
+    # bf16 rounding of an fp32-accumulated sum: half an ulp of bf16 (2^-9) of the value
+    assert ((out.float() - want).abs() <= want.abs() * 2 ** -8 + 1e-6).all()
+
+
+def test_cross_forward_epilogue(dev):
+    from recommendation_amd import ops
+    M, d = 384, 448
+    g = torch.Generator(device='cpu').manual_seed(1)
+    x0 = (torch.randn((M, d), generator=g)).to(torch.bfloat16).to(dev)
+    xl = (torch.randn((M, d), generator=g)).to(torch.bfloat16).to(dev)
+    W = (torch.randn((d, d), generator=g) / d ** 0.5).to(torch.bfloat16).to(dev)
+    bias = torch.randn(d, generator=g).to(dev)
+    u = torch.empty((M, d), dtype=torch.bfloat16, device=dev)
+    xn = torch.empty((M, d), dtype=torch.bfloat16, device=dev)
+    ops.gemm_bf16(xl, W, ops.MI_EPI_CROSS_FWD, out=xn, out1=u, bias=bias, in0=x0, in1=xl)
+    u_want = xl.float() @ W.float().t() + bias
+    x_want = x0.float() * u_want + xl.float()
+    assert (u.float() - u_want).abs().max() <= 1e-2 * u_want.abs().max()
+    assert (xn.float() - x_want).abs().max() <= 1e-2 * x_want.abs().max()
+
+
+def test_mask_and_cross_backward_epilogues(dev):
+    from recommendation_amd import ops
+    M, N, K = 256, 448, 1024                       # dX[M, N] = dY[M, K] * W[K, N]  (W reduction-major)
+    g = torch.Generator(device='cpu').manual_seed(2)
+    dY = _ints((M, K), dev, 5, -2, 3)
+    W = _ints((K, N), dev, 6, -2, 3)
+    H = torch.randn((M, N), generator=g).to(torch.bfloat16).to(dev)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm_bf16(dY, W, ops.MI_EPI_MASK, b_rm=True, out=out, in0=H)
+    want = (dY.float() @ W.float()) * (H.float() > 0)
+    assert torch.equal(out.float(), want.to(torch.bfloat16).float())
+    # cross backward: v = C + R; out = v; out1 = v*x0; facc = (init) v*u, then += on a second call
+    R, x0, u = _ints((M, N), dev, 7), _ints((M, N), dev, 8), _ints((M, N), dev, 9)
+    dx = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    du = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    facc = torch.full((M, N), float('nan'), dtype=torch.float32, device=dev)
+    ops.gemm_bf16(dY, W, ops.MI_EPI_CROSS_BWD, b_rm=True, flags=ops.MI_EPI_INIT, out=dx, in1=R, in0=x0, in2=u,
+                  out1=du, facc=facc)
+    v = dY.float() @ W.float() + R.float()
+    assert torch.equal(dx.float(), v.to(torch.bfloat16).float())
+    assert torch.equal(du.float(), (v * x0.float()).to(torch.bfloat16).float())
+    assert torch.equal(facc, v * u.float())
+    ops.gemm_bf16(dY, W, ops.MI_EPI_CROSS_BWD, b_rm=True, out=None, in1=R, facc=facc)
+    assert torch.equal(facc, v * u.float() + v)
+
+
+def test_rejects_bad_shapes(dev):
+    from recommendation_amd import ops
+    from recommendation_amd._lib import MiError
+    A = torch.zeros((64, 100), dtype=torch.bfloat16, device=dev)
+    out = torch.zeros((1, 64, 64), dtype=torch.float32, device=dev)
+    with pytest.raises(MiError):
+        ops.gemm_bf16(A, A, ops.MI_EPI_SLAB, out=out)          # K = 100 is not a multiple of 64
