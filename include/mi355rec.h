@@ -380,6 +380,40 @@ int mi_gemm_bf16(int a_reduction_major, int b_reduction_major, int64_t M, int64_
                  const void* A, int64_t lda, const void* B, int64_t ldb, int k_splits,
                  const mi_gemm_epilogue* epi, void* stream);
 
+/* Memory-bound pieces around the contractions (all sums in a fixed order, no float atomics). */
+
+/* x[b][col0+j] = bf16(dense[b][j]) for j < n_dense, zero up to column d_pad: the dense-feature
+ * tail of the interaction input row whose head mi_embag_fwd (out_dtype MI_DT_BF16) writes. */
+int mi_pack_dense_bf16(const float* dense, int n_dense, int64_t B, void* x, int64_t ld, int col0,
+                       int d_pad, void* stream);
+
+/* partial[s][n] = sum of X[m][n] (bf16) over the rows of slice s (slices of ceil(M/slices)
+ * rows): bias gradients, finished by mi_slab_adam. */
+int mi_colsum_bf16(const void* X, int64_t ld, int64_t M, int N, int slices, float* partial,
+                   int64_t ld_partial, void* stream);
+
+/* g[i] = sum_s slab[s*slab_stride + i] (s ascending), then tf.train.AdamOptimizer's update
+ * (model_trainer.py:157; the form of mi_adam_tf_dense) on the fp32 master w with state m, v,
+ * and w_bf16[i] = bf16(w[i]) for the next contraction.  grad_out (optional) receives g; with
+ * w == NULL only grad_out is written. */
+int mi_slab_adam(const float* slab, int n_slabs, int64_t n, int64_t slab_stride, float* w, float* m,
+                 float* v, float lr_t, const float* lr_dev, float beta1, float beta2, float eps,
+                 void* w_bf16, float* grad_out, void* stream);
+
+/* 1-wide output layer on bf16 activations h[B][K]: logit = h.w + bias, BCE-with-logits loss
+ * rows and g = (sigmoid(logit) - y) * gscale. */
+int mi_head_fwd(const void* h, int64_t ld, int K, const float* w, const float* bias,
+                const float* labels, float gscale, int64_t B, float* logit, float* loss_rows,
+                float* g, void* stream);
+/* Its backward: dh[b][k] = g[b]*w[k] where h[b][k] > 0 else 0 (h is a ReLU output), and
+ * partial[s][0..K) = sum_b g[b]*h[b][k], partial[s][K] = sum_b g[b] over slice s. */
+int mi_head_bwd(const float* g, const float* w, const void* h, int64_t ld_h, int K, int64_t B,
+                void* dh, int64_t ld_dh, int slices, float* partial, int64_t ld_partial,
+                void* stream);
+
+/* out (bf16) = in (fp32). */
+int mi_cast_bf16(const float* in, int64_t n, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

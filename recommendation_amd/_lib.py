@@ -82,6 +82,12 @@ _SIGNATURES = {
     'mi_adam_schedule_step': (c_int, [P, c_float, c_float, c_float, P]),
     'mi_gemm_bf16': (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, c_int,
                              POINTER(GemmEpilogue), P]),
+    'mi_pack_dense_bf16': (c_int, [P, c_int, c_int64, P, c_int64, c_int, c_int, P]),
+    'mi_colsum_bf16': (c_int, [P, c_int64, c_int64, c_int, c_int, P, c_int64, P]),
+    'mi_slab_adam': (c_int, [P, c_int, c_int64, c_int64, P, P, P, c_float, P, c_float, c_float, c_float, P, P, P]),
+    'mi_head_fwd': (c_int, [P, c_int64, c_int, P, P, P, c_float, c_int64, P, P, P, P]),
+    'mi_head_bwd': (c_int, [P, P, P, c_int64, c_int, c_int64, P, c_int64, c_int, P, c_int64, P]),
+    'mi_cast_bf16': (c_int, [P, c_int64, P, P]),
     'mi_shard_block_ints': (c_int64, [c_int64, c_int]),
     'mi_shard_route': (c_int, [P, c_int, P, c_int, c_int64, c_int, P, P, P]),
     'mi_fm_partial_fwd': (c_int, [POINTER(FmTable), c_int64, P, c_int, c_int64, c_int, P, P, P, P, P, P]),

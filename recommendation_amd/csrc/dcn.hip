@@ -1,0 +1,239 @@
+// Memory-bound pieces around the bf16 contractions of the DCN-v2 / DIN dense side: packing the
+// dense features into the bf16 input row, column sums (bias gradients), the split-K slab
+// reduction fused with TensorFlow-form Adam (recommendation/code/model_trainer.py:157) and the
+// bf16 re-cast of the weights, and the 1-wide output layer with its BCE loss.  None of this is
+// in the reference (its network is 5,910 fp32 parameters, recommendation/code/r_model.py:24-58).
+// Every sum has a fixed order; nothing uses float atomics.
+#include "common.h"
+
+namespace {
+
+// x[b][col0 + j] = bf16(dense[b][j]) for j < nd, zero for col0+nd <= col < d_pad
+__global__ __launch_bounds__(256) void pack_dense_kernel(const float* __restrict__ dense, int nd, int64_t B,
+                                                        unsigned short* __restrict__ x, int64_t ld, int col0,
+                                                        int d_pad) {
+  const int w = d_pad - col0;
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * w) return;
+  const int64_t b = i / w;
+  const int j = (int) (i - b * w);
+  x[b * ld + col0 + j] = j < nd ? mi_f2bf(dense[b * nd + j]) : (unsigned short) 0;
+}
+
+// partial[s][n] = sum over rows of slice s of X[m][n]; thread per 4 columns, fixed row order
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* __restrict__ X, int64_t ld, int64_t M,
+                                                         int N, int rows_per_slice, float* __restrict__ partial,
+                                                         int64_t ld_partial) {
+  const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (n >= N) return;
+  const int s = blockIdx.y;
+  const int64_t lo = (int64_t) s * rows_per_slice;
+  const int64_t hi = lo + rows_per_slice < M ? lo + rows_per_slice : M;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t m = lo; m < hi; ++m) {
+    const ushort4 u = *reinterpret_cast<const ushort4*>(X + m * ld + n);
+    acc.x += mi_bf2f(u.x); acc.y += mi_bf2f(u.y); acc.z += mi_bf2f(u.z); acc.w += mi_bf2f(u.w);
+  }
+  *reinterpret_cast<float4*>(partial + (int64_t) s * ld_partial + n) = acc;
+}
+
+// g = sum_s slab[s][i] (s ascending) -> TensorFlow-form Adam on the fp32 master -> bf16 copy
+__global__ __launch_bounds__(256) void slab_adam_kernel(const float* __restrict__ slab, int S, int64_t n,
+                                                       int64_t slab_stride, float* __restrict__ w,
+                                                       float* __restrict__ m, float* __restrict__ v, float lr_t,
+                                                       const float* __restrict__ lr_dev, float b1, float b2, float eps,
+                                                       unsigned short* __restrict__ w_bf16,
+                                                       float* __restrict__ grad_out) {
+  const int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < S; ++s) {
+    const float4 p = *reinterpret_cast<const float4*>(slab + (int64_t) s * slab_stride + i);
+    g.x += p.x; g.y += p.y; g.z += p.z; g.w += p.w;
+  }
+  if (grad_out) *reinterpret_cast<float4*>(grad_out + i) = g;
+  if (!w) return;
+  const float alpha = lr_dev ? lr_dev[0] : lr_t;
+  float4 wi = *reinterpret_cast<const float4*>(w + i);
+  float4 mi = *reinterpret_cast<const float4*>(m + i);
+  float4 vi = *reinterpret_cast<const float4*>(v + i);
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+#define ADAM1(c)                                   \
+  mi.c += (g.c - mi.c) * omb1;                     \
+  vi.c += (g.c * g.c - vi.c) * omb2;               \
+  wi.c -= (mi.c * alpha) / (sqrtf(vi.c) + eps);
+  ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+  *reinterpret_cast<float4*>(w + i) = wi;
+  *reinterpret_cast<float4*>(m + i) = mi;
+  *reinterpret_cast<float4*>(v + i) = vi;
+  if (w_bf16) {
+    ushort4 u;
+    u.x = mi_f2bf(wi.x); u.y = mi_f2bf(wi.y); u.z = mi_f2bf(wi.z); u.w = mi_f2bf(wi.w);
+    *reinterpret_cast<ushort4*>(w_bf16 + i) = u;
+  }
+}
+
+// Output layer, one wave per sample: logit = h . w + bias; BCE-with-logits loss row; g = dL/dlogit.
+__global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned short* __restrict__ h, int64_t ld, int K,
+                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const float* __restrict__ labels, float gscale, int64_t B,
+                                                      float* __restrict__ logit, float* __restrict__ loss_rows,
+                                                      float* __restrict__ g) {
+  const int64_t b = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63;
+  float acc = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const ushort4 u = *reinterpret_cast<const ushort4*>(h + b * ld + k);
+    const float4 ww = *reinterpret_cast<const float4*>(w + k);
+    acc = fmaf(mi_bf2f(u.x), ww.x, acc); acc = fmaf(mi_bf2f(u.y), ww.y, acc);
+    acc = fmaf(mi_bf2f(u.z), ww.z, acc); acc = fmaf(mi_bf2f(u.w), ww.w, acc);
+  }
+  acc = mi_wave_sum(acc);
+  if (lane != 0) return;
+  const float z = acc + (bias ? bias[0] : 0.f);
+  if (logit) logit[b] = z;
+  if (labels) {
+    const float y = labels[b];
+    const float e = expf(-fabsf(z));
+    if (loss_rows) loss_rows[b] = fmaxf(z, 0.f) - z * y + log1pf(e);
+    const float sig = z >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+    if (g) g[b] = (sig - y) * gscale;
+  }
+}
+
+// dh[b][k] = g[b] * w[k] where h[b][k] > 0 (ReLU of the layer that produced h), else 0
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                      const unsigned short* __restrict__ h, int64_t ld_h, int K,
+                                                      int64_t B, unsigned short* __restrict__ dh, int64_t ld_dh) {
+  const int kq = K / 4;
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * kq) return;
+  const int64_t b = i / kq;
+  const int k = (int) (i - b * kq) * 4;
+  const float gb = g[b];
+  const float4 ww = *reinterpret_cast<const float4*>(w + k);
+  const ushort4 hh = *reinterpret_cast<const ushort4*>(h + b * ld_h + k);
+  ushort4 o;
+  o.x = mi_bf2f(hh.x) > 0.f ? mi_f2bf(gb * ww.x) : (unsigned short) 0;
+  o.y = mi_bf2f(hh.y) > 0.f ? mi_f2bf(gb * ww.y) : (unsigned short) 0;
+  o.z = mi_bf2f(hh.z) > 0.f ? mi_f2bf(gb * ww.z) : (unsigned short) 0;
+  o.w = mi_bf2f(hh.w) > 0.f ? mi_f2bf(gb * ww.w) : (unsigned short) 0;
+  *reinterpret_cast<ushort4*>(dh + b * ld_dh + k) = o;
+}
+
+// partial[s][k] = sum over samples of slice s of g[b]*h[b][k] (k < K);  partial[s][K] = sum g[b]
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ g,
+                                                        const unsigned short* __restrict__ h, int64_t ld, int K,
+                                                        int64_t B, int rows_per_slice, float* __restrict__ partial,
+                                                        int64_t ld_partial) {
+  const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (k >= K + 4) return;
+  const int s = blockIdx.y;
+  const int64_t lo = (int64_t) s * rows_per_slice;
+  const int64_t hi = lo + rows_per_slice < B ? lo + rows_per_slice : B;
+  float* out = partial + (int64_t) s * ld_partial;
+  if (k >= K) {  // the bias column
+    float acc = 0.f;
+    for (int64_t b = lo; b < hi; ++b) acc += g[b];
+    out[K] = acc;
+    return;
+  }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t b = lo; b < hi; ++b) {
+    const float gb = g[b];
+    const ushort4 u = *reinterpret_cast<const ushort4*>(h + b * ld + k);
+    acc.x = fmaf(gb, mi_bf2f(u.x), acc.x); acc.y = fmaf(gb, mi_bf2f(u.y), acc.y);
+    acc.z = fmaf(gb, mi_bf2f(u.z), acc.z); acc.w = fmaf(gb, mi_bf2f(u.w), acc.w);
+  }
+  *reinterpret_cast<float4*>(out + k) = acc;
+}
+
+// out (bf16) = in (fp32), n multiple of 4
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ in, int64_t n,
+                                                       unsigned short* __restrict__ out) {
+  const int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float4 f = *reinterpret_cast<const float4*>(in + i);
+  ushort4 u;
+  u.x = mi_f2bf(f.x); u.y = mi_f2bf(f.y); u.z = mi_f2bf(f.z); u.w = mi_f2bf(f.w);
+  *reinterpret_cast<ushort4*>(out + i) = u;
+}
+
+bool a16(const void* p) { return ((uintptr_t) p & 15) == 0; }
+bool a8(const void* p) { return ((uintptr_t) p & 7) == 0; }
+
+}  // namespace
+
+extern "C" int mi_pack_dense_bf16(const float* dense, int n_dense, int64_t B, void* x, int64_t ld, int col0,
+                                  int d_pad, void* stream) {
+  MI_REQUIRE(x && B >= 0 && n_dense >= 0 && col0 >= 0 && col0 + n_dense <= d_pad && d_pad <= ld &&
+                 (n_dense == 0 || dense),
+             "mi_pack_dense_bf16: bad arguments");
+  const int64_t n = B * (d_pad - col0);
+  if (n == 0) return MI_OK;
+  hipLaunchKernelGGL(pack_dense_kernel, dim3((unsigned) mi_cdiv(n, 256)), dim3(256), 0, (hipStream_t) stream, dense,
+                     n_dense, B, (unsigned short*) x, ld, col0, d_pad);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_colsum_bf16(const void* X, int64_t ld, int64_t M, int N, int slices, float* partial,
+                              int64_t ld_partial, void* stream) {
+  MI_REQUIRE(X && partial && M >= 1 && N >= 4 && N % 4 == 0 && ld % 4 == 0 && a8(X) && a16(partial) &&
+                 ld_partial % 4 == 0 && ld_partial >= N && slices >= 1 && slices <= 65535,
+             "mi_colsum_bf16: bad arguments");
+  const int rps = (int) mi_cdiv(M, slices);
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned) mi_cdiv(N / 4, 256), (unsigned) slices), dim3(256), 0,
+                     (hipStream_t) stream, (const unsigned short*) X, ld, M, N, rps, partial, ld_partial);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_slab_adam(const float* slab, int n_slabs, int64_t n, int64_t slab_stride, float* w, float* m,
+                            float* v, float lr_t, const float* lr_dev, float beta1, float beta2, float eps,
+                            void* w_bf16, float* grad_out, void* stream) {
+  MI_REQUIRE(slab && n_slabs >= 1 && n >= 4 && n % 4 == 0 && slab_stride % 4 == 0 && slab_stride >= n && a16(slab),
+             "mi_slab_adam: slabs must be 16-byte aligned, n a multiple of 4");
+  MI_REQUIRE((w && m && v && a16(w) && a16(m) && a16(v)) || (!w && grad_out), "mi_slab_adam: need w, m, v or grad_out");
+  MI_REQUIRE((!w_bf16 || a8(w_bf16)) && (!grad_out || a16(grad_out)), "mi_slab_adam: misaligned output");
+  hipLaunchKernelGGL(slab_adam_kernel, dim3((unsigned) mi_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t) stream, slab,
+                     n_slabs, n, slab_stride, w, m, v, lr_t, lr_dev, beta1, beta2, eps, (unsigned short*) w_bf16,
+                     grad_out);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_head_fwd(const void* h, int64_t ld, int K, const float* w, const float* bias, const float* labels,
+                           float gscale, int64_t B, float* logit, float* loss_rows, float* g, void* stream) {
+  MI_REQUIRE(h && w && B >= 1 && K >= 4 && K % 4 == 0 && ld % 4 == 0 && a8(h) && a16(w), "mi_head_fwd: bad arguments");
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned) mi_cdiv(B, 4)), dim3(256), 0, (hipStream_t) stream,
+                     (const unsigned short*) h, ld, K, w, bias, labels, gscale, B, logit, loss_rows, g);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_head_bwd(const float* g, const float* w, const void* h, int64_t ld_h, int K, int64_t B, void* dh,
+                           int64_t ld_dh, int slices, float* partial, int64_t ld_partial, void* stream) {
+  MI_REQUIRE(g && w && h && dh && partial && B >= 1 && K >= 4 && K % 4 == 0 && ld_h % 4 == 0 && ld_dh % 4 == 0 &&
+                 a8(h) && a8(dh) && a16(w) && a16(partial) && ld_partial % 4 == 0 && ld_partial >= K + 4 &&
+                 slices >= 1 && slices <= 65535,
+             "mi_head_bwd: bad arguments");
+  hipStream_t s = (hipStream_t) stream;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned) mi_cdiv(B * (K / 4), 256)), dim3(256), 0, s, g, w,
+                     (const unsigned short*) h, ld_h, K, B, (unsigned short*) dh, ld_dh);
+  const int rps = (int) mi_cdiv(B, slices);
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned) mi_cdiv(K / 4 + 1, 256), (unsigned) slices), dim3(256), 0, s, g,
+                     (const unsigned short*) h, ld_h, K, B, rps, partial, ld_partial);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_cast_bf16(const float* in, int64_t n, void* out, void* stream) {
+  MI_REQUIRE(in && out && n >= 4 && n % 4 == 0 && a16(in) && a8(out), "mi_cast_bf16: bad arguments");
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned) mi_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t) stream, in, n,
+                     (unsigned short*) out);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}

@@ -13,8 +13,10 @@
 // transposing read (ds_read_b64_tr_b16), so no transposed copy of any activation or weight is
 // ever written to HBM.
 //
-// Tile 128x128x64, 4 waves as 2x2, each wave 4x4 fragments of mfma_f32_16x16x32_bf16,
-// register-staged global loads one tile ahead, two LDS buffers, one barrier per K tile.
+// Each wave owns a 64x64 block of the result (4x4 fragments of mfma_f32_16x16x32_bf16); a
+// workgroup is WM x WN waves (256x128x64 tiles with 8 waves for the big contractions, 128x128x64
+// with 4 for narrow ones).  Tiles are staged global -> LDS by DMA up to STAGES-1 tiles ahead,
+// retired with counted vmcnt waits and ONE raw barrier per K tile.
 #include "common.h"
 
 namespace {
@@ -25,8 +27,8 @@ typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s4v* lds_s4v_ptr;
 
-constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per buffer
+constexpr int BK = 64;
+constexpr int SUB_BYTES = 128 * BK * 2;  // an operand tile is made of 128-row sub-tiles of 16 KiB
 
 // LDS image of a reduction-contiguous tile: [128 rows][64 k] = 128-byte rows of eight 16-byte
 // chunks; chunk position XORed with the row so that the 16 rows of a fragment spread over banks.
@@ -37,36 +39,45 @@ __device__ __forceinline__ int tr_img(int kr, int ch) {
   return kr * 256 + ((ch ^ (((kr & 3) << 2) | ((kr >> 2) & 3))) << 4);
 }
 
-// Staging: each thread moves four 16-byte chunks per operand and K tile, global -> registers ->
-// LDS.  Chunk i of thread t is chunk c = t + 256*i of the tile.
-// rows [row0, row0+128) x k [k0, k0+64) of an operand with R rows in total
-template <bool TR>
-__device__ __forceinline__ uint4 load_chunk(const unsigned short* __restrict__ P, int64_t ld, int64_t row0, int64_t R,
-                                            int64_t k0, int i) {
-  const int c = threadIdx.x + NTHREADS * i;
-  if constexpr (!TR) {
-    const int r = c >> 3, ch = c & 7;
-    int64_t rr = row0 + r;
-    rr = rr < R ? rr : R - 1;  // out-of-range rows read a valid row; their results are never stored
-    return *reinterpret_cast<const uint4*>(P + rr * ld + k0 + ch * 8);
-  } else {
-    const int kr = c >> 4, ch = c & 15;
-    int64_t m = row0 + ch * 8;
-    m = m <= R - 8 ? m : R - 8;
-    return *reinterpret_cast<const uint4*>(P + (k0 + kr) * ld + m);
+// Staging: global -> LDS directly (LDS-DMA, global_load_lds_dwordx4), no registers and no
+// ds_write in between.  One wave-instruction deposits 64 x 16 bytes at a wave-uniform LDS base
+// + lane*16, i.e. it fills LDS linearly; the XOR of the images above is therefore applied to
+// the SOURCE address (lane -> which chunk of which row it fetches).  A 16 KiB sub-tile is 16
+// such 1 KiB pieces; the tile's pieces are dealt round-robin over the workgroup's waves.
+// rows [row0, row0 + 128*NSUB) x k [k0, k0+64) of an operand with R rows in total
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <bool TR, int NSUB, int NWAVES>
+__device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ P, int64_t ld, int64_t row0, int64_t R,
+                                           int64_t k0, char* lds, int wave, int lane) {
+  constexpr int PER_WAVE = NSUB * 16 / NWAVES;
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int gp = __builtin_amdgcn_readfirstlane(wave + NWAVES * i);  // piece of the whole tile
+    const int sub = gp >> 4, piece = gp & 15;
+    const unsigned short* src;
+    if constexpr (!TR) {
+      const int r = piece * 8 + (lane >> 3), ch = (lane & 7) ^ (r & 7);
+      int64_t rr = row0 + sub * 128 + r;
+      rr = rr < R ? rr : R - 1;  // out-of-range rows read a valid row; their results are never stored
+      src = P + rr * ld + k0 + ch * 8;
+    } else {
+      const int kr = piece * 4 + (lane >> 4), ch = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+      int64_t m = row0 + sub * 128 + ch * 8;
+      m = m <= R - 8 ? m : R - 8;
+      src = P + (k0 + kr) * ld + m;
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t) src, (lptr_t) (lds + gp * 1024), 16, 0, 0);
   }
-}
-template <bool TR>
-__device__ __forceinline__ void store_chunk(char* lds, int i, uint4 v) {
-  const int c = threadIdx.x + NTHREADS * i;
-  const int off = TR ? tr_img(c >> 4, c & 15) : row_img(c >> 3, c & 7);
-  *reinterpret_cast<uint4*>(lds + off) = v;
 }
 
 // fragment f (16 rows of the tile), k-step kk (32 of the tile's 64 k): lane l gets row l&15,
 // k = 8*(l>>4) + 0..7
 template <bool TR>
-__device__ __forceinline__ s8v read_frag(const char* lds, int f, int kk, int lane) {
+__device__ __forceinline__ s8v read_frag(const char* tile, int frag, int kk, int lane) {
+  const char* lds = tile + (frag >> 3) * SUB_BYTES;
+  const int f = frag & 7;
   if constexpr (!TR) {
     const int r = f * 16 + (lane & 15), ch = kk * 4 + (lane >> 4);
     return *reinterpret_cast<const s8v*>(lds + row_img(r, ch));
@@ -161,11 +172,23 @@ __device__ __forceinline__ void epilogue(const mi_gemm_epilogue& e, int64_t M, i
   }
 }
 
-template <bool A_TR, bool B_TR>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs a) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <bool A_TR, bool B_TR, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64, 1) void gemm_bf16_kernel(GemmArgs a) {
+  constexpr int NWAVES = WM * WN, BM = 64 * WM, BN = 64 * WN;
+  constexpr int A_SUB = BM / 128, B_SUB = BN / 128;
+  constexpr int A_BYTES = A_SUB * SUB_BYTES, B_BYTES = B_SUB * SUB_BYTES;
+  constexpr int PER_TILE = (A_SUB + B_SUB) * 16 / NWAVES;  // DMA instructions per wave and K tile
+  constexpr int D = STAGES - 1;                             // tiles in flight ahead of the one being multiplied
+  static_assert(BM % 128 == 0 && BN % 128 == 0 && (A_SUB * 16) % NWAVES == 0 && (B_SUB * 16) % NWAVES == 0, "tile");
+  static_assert(D >= 1 && D <= 3, "stages");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const As = smem;                   // two buffers of TILE_BYTES
-  char* const Bs = smem + 2 * TILE_BYTES;  // two buffers of TILE_BYTES
+  char* const As = smem;                     // STAGES buffers of A_BYTES
+  char* const Bs = smem + STAGES * A_BYTES;  // STAGES buffers of B_BYTES
   // consecutive workgroup ids go round-robin over the 8 XCDs; renumber so that each XCD (its own
   // L2) works on consecutive tiles, i.e. the n-tiles that share one A row block
   const int nb = gridDim.x, id = blockIdx.x, xcd = id & 7, q = nb >> 3, r = nb & 7;
@@ -176,7 +199,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs a) {
   const int64_t kbeg = (int64_t) z * a.k_per_split;
   const int64_t kend = kbeg + a.k_per_split < a.K ? kbeg + a.k_per_split : a.K;
   const int ktiles = (int) ((kend - kbeg) / BK);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w / WN, wc = w % WN;
 
   f4v acc[4][4];
 #pragma unroll
@@ -184,38 +207,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
 
-#define LOAD_TILE(k0_)                                         \
-  a0 = load_chunk<A_TR>(a.A, a.lda, m0, a.M, (k0_), 0);        \
-  a1 = load_chunk<A_TR>(a.A, a.lda, m0, a.M, (k0_), 1);        \
-  a2 = load_chunk<A_TR>(a.A, a.lda, m0, a.M, (k0_), 2);        \
-  a3 = load_chunk<A_TR>(a.A, a.lda, m0, a.M, (k0_), 3);        \
-  b0 = load_chunk<B_TR>(a.B, a.ldb, n0, a.N, (k0_), 0);        \
-  b1 = load_chunk<B_TR>(a.B, a.ldb, n0, a.N, (k0_), 1);        \
-  b2 = load_chunk<B_TR>(a.B, a.ldb, n0, a.N, (k0_), 2);        \
-  b3 = load_chunk<B_TR>(a.B, a.ldb, n0, a.N, (k0_), 3);
-#define STORE_TILE(buf_)                                       \
-  store_chunk<A_TR>(As + (buf_) * TILE_BYTES, 0, a0);          \
-  store_chunk<A_TR>(As + (buf_) * TILE_BYTES, 1, a1);          \
-  store_chunk<A_TR>(As + (buf_) * TILE_BYTES, 2, a2);          \
-  store_chunk<A_TR>(As + (buf_) * TILE_BYTES, 3, a3);          \
-  store_chunk<B_TR>(Bs + (buf_) * TILE_BYTES, 0, b0);          \
-  store_chunk<B_TR>(Bs + (buf_) * TILE_BYTES, 1, b1);          \
-  store_chunk<B_TR>(Bs + (buf_) * TILE_BYTES, 2, b2);          \
-  store_chunk<B_TR>(Bs + (buf_) * TILE_BYTES, 3, b3);
-  uint4 a0, a1, a2, a3, b0, b1, b2, b3;
-  LOAD_TILE(kbeg)
-  STORE_TILE(0)
-  __syncthreads();
+#define STAGE(kt_, buf_)                                                                                             \
+  do {                                                                                                               \
+    const int64_t k0_ = kbeg + (int64_t) (kt_) * BK;                                                                 \
+    stage_tile<A_TR, A_SUB, NWAVES>(a.A, a.lda, m0, a.M, k0_, As + (buf_) * A_BYTES, w, lane);                       \
+    stage_tile<B_TR, B_SUB, NWAVES>(a.B, a.ldb, n0, a.N, k0_, Bs + (buf_) * B_BYTES, w, lane);                       \
+  } while (0)
+
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < ktiles) STAGE(s, s);
+  int cur = 0;  // buffer of tile kt
   for (int kt = 0; kt < ktiles; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < ktiles;
-    // always issued (the last iteration re-reads its own tile) so that the staging registers are
-    // written unconditionally and stay registers
-    const int64_t knext = kbeg + (int64_t) (more ? kt + 1 : kt) * BK;
-    LOAD_TILE(knext)
-    __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the MFMAs: they fly while the tile is computed
-    const char* Ac = As + cur * TILE_BYTES;
-    const char* Bc = Bs + cur * TILE_BYTES;
+    // Tile kt must have landed; the younger tiles already issued (at most D-1 of them) may stay in
+    // flight.  Each wave waits for its own DMA, the barrier then covers everybody's - and also
+    // tells that every wave is done reading the buffer that is restaged right below.
+    const int younger = (kt + D - 1 < ktiles ? kt + D - 1 : ktiles - 1) - kt;
+    if (D >= 3 && younger == 2) wait_vmcnt<2 * PER_TILE>();
+    else if (D >= 2 && younger == 1) wait_vmcnt<PER_TILE>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + D < ktiles) {
+      int nxt = cur + D;
+      nxt = nxt >= STAGES ? nxt - STAGES : nxt;
+      STAGE(kt + D, nxt);
+    }
+    const char* Ac = As + cur * A_BYTES;
+    const char* Bc = Bs + cur * B_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       s8v fa[4], fb[4];
@@ -231,14 +250,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, fb[j]),
                                                               __builtin_bit_cast(bf8v, fa[i]), acc[i][j], 0, 0, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) {
-      STORE_TILE(cur ^ 1)
-    }
-    __syncthreads();
+    cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
-#undef LOAD_TILE
-#undef STORE_TILE
+#undef STAGE
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t m = m0 + wr * 64 + i * 16 + (lane & 15);
@@ -248,6 +262,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs a) {
       if (m < a.M && n < a.N) epilogue(a.e, a.M, a.N, z, m, n, make_float4(acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w));
     }
   }
+}
+
+template <bool A_TR, bool B_TR, int WM, int WN, int STAGES>
+int launch_gemm(GemmArgs& g, int splits, hipStream_t s) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr size_t lds = (size_t) STAGES * (BM + BN) * BK * 2;
+  static bool configured = false;  // per instantiation; racing first calls set the same value
+  if (lds > 64 * 1024 && !configured) {
+    MI_HIP(hipFuncSetAttribute((const void*) gemm_bf16_kernel<A_TR, B_TR, WM, WN, STAGES>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    configured = true;
+  }
+  g.tiles_n = (int) mi_cdiv(g.N, BN);
+  const int64_t tiles = mi_cdiv(g.M, BM) * g.tiles_n;
+  MI_REQUIRE(tiles < ((int64_t) 1 << 31), "mi_gemm_bf16: too many tiles");
+  hipLaunchKernelGGL((gemm_bf16_kernel<A_TR, B_TR, WM, WN, STAGES>), dim3((unsigned) tiles, (unsigned) splits),
+                     dim3(WM * WN * 64), lds, s, g);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+template <bool A_TR, bool B_TR>
+int dispatch_gemm(GemmArgs& g, int splits, hipStream_t s) {
+  // 128x128 tiles, two stages, two workgroups per CU.  A 256x128 tile with three stages (8 waves,
+  // 144 KiB of LDS, one workgroup per CU) was measured 4-13 % SLOWER on the 65536-row shapes here
+  // (609 vs 634 TFLOP/s forward, 568 vs 654 for the weight gradient), so it is not instantiated.
+  return launch_gemm<A_TR, B_TR, 2, 2, 2>(g, splits, s);
 }
 
 bool al16p(const void* p) { return ((uintptr_t) p & 15) == 0; }
@@ -302,21 +343,11 @@ extern "C" int mi_gemm_bf16(int a_reduction_major, int b_reduction_major, int64_
   g.A = (const unsigned short*) A;
   g.B = (const unsigned short*) B;
   g.lda = lda; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.k_per_split = k_per;
-  g.tiles_n = (int) mi_cdiv(N, BN);
+  g.tiles_n = 0;
   g.e = e;
-  const int64_t tiles = mi_cdiv(M, BM) * g.tiles_n;
-  MI_REQUIRE(tiles < ((int64_t) 1 << 31), "%s: too many tiles", who);
-  const dim3 grid((unsigned) tiles, (unsigned) splits), block(NTHREADS);
-  const size_t lds = 4 * TILE_BYTES;
   hipStream_t s = (hipStream_t) stream;
-  if (!a_reduction_major && !b_reduction_major)
-    hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, lds, s, g);
-  else if (!a_reduction_major && b_reduction_major)
-    hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, lds, s, g);
-  else if (a_reduction_major && b_reduction_major)
-    hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, lds, s, g);
-  else
-    hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, lds, s, g);
-  MI_LAUNCH_CHECK();
-  return MI_OK;
+  if (!a_reduction_major && !b_reduction_major) return dispatch_gemm<false, false>(g, splits, s);
+  if (!a_reduction_major && b_reduction_major) return dispatch_gemm<false, true>(g, splits, s);
+  if (a_reduction_major && b_reduction_major) return dispatch_gemm<true, true>(g, splits, s);
+  return dispatch_gemm<true, false>(g, splits, s);
 }

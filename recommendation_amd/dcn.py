@@ -1,0 +1,254 @@
+"""DCN-v2 on Criteo-shaped input: host side of the bf16 matrix-core path.
+
+The reference has no DCN (recommendation/code/r_model.py:24-58 is a linear network trained with
+tf.train.AdamOptimizer, recommendation/code/model_trainer.py:157); this is the interaction model
+the benchmark definition adds on top of the same building blocks:
+
+  x0       = [ 26 embedding rows (mi_embag_fwd, written as bf16) | 13 dense features | zero pad ]
+  x_{l+1}  = x0 * (W_l x_l + b_l) + x_l        3 full-rank cross layers   (mi_gemm_bf16, fused epilogue)
+  h_{i+1}  = relu(W_i h_i + b_i)               MLP                        (mi_gemm_bf16, fused epilogue)
+  logit    = w . h + b, BCE loss                                          (mi_head_fwd)
+
+The input width 26*16+13 = 429 is padded to 448 (a multiple of the 64-deep contraction tile);
+padded weights and activations are zero and stay zero.  Activations and the weights' working
+copies are bf16, accumulation and the master weights fp32.  The backward never writes a
+transposed tensor: dX = dY*W and dW = dY^T*X read their operands as they lie in memory through
+the transposing LDS read.  dW is produced as split-K fp32 slabs, which one kernel per parameter
+sums in a fixed order, feeds to TensorFlow-form Adam and re-casts to bf16.  The embedding side is
+the same deterministic sort-by-row scatter and fused row-wise Adagrad as everywhere else.
+"""
+import math
+
+import torch
+
+from . import ops
+
+
+def _round_up(x, m):
+    return -(-x // m) * m
+
+
+class _Dense(object):
+    """One dense parameter: fp32 master + Adam state (+ bf16 working copy for matrices)."""
+
+    def __init__(self, value, device, bf16_copy):
+        self.w = value.to(device=device, dtype=torch.float32).contiguous()
+        self.m, self.v = torch.zeros_like(self.w), torch.zeros_like(self.w)
+        self.grad = torch.zeros_like(self.w)
+        self.h = self.w.to(torch.bfloat16) if bf16_copy else None
+
+
+class DCNv2(object):
+    def __init__(self, rows_per_table, dim, n_dense, device, n_cross=3, mlp=(1024, 1024, 512), lr=1e-3, emb_lr=1e-2,
+                 beta1=0.9, beta2=0.999, eps=1e-8, emb_eps=1e-8, seed=0, keep_grads=False):
+        self.device = torch.device(device)
+        self.rows_per_table = [int(r) for r in rows_per_table]
+        self.T, self.dim, self.n_dense = len(self.rows_per_table), int(dim), int(n_dense)
+        self.total_rows = sum(self.rows_per_table)
+        self.toffs = ops.table_offsets(self.rows_per_table, self.device)
+        self.d = self.T * self.dim + self.n_dense
+        self.dp = _round_up(self.d, 64)
+        self.n_cross, self.mlp = int(n_cross), [int(w) for w in mlp]
+        for w in self.mlp:
+            if w % 64:
+                raise ValueError("MLP widths must be multiples of 64")
+        self.lr, self.emb_lr, self.beta1, self.beta2, self.eps, self.emb_eps = lr, emb_lr, beta1, beta2, eps, emb_eps
+        self.keep_grads = keep_grads
+        gen = torch.Generator(device='cpu')
+        gen.manual_seed(seed)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.V = torch.randn((self.total_rows, self.dim), generator=gen).mul_(0.05).to(self.device)
+        self.V_acc = torch.zeros((self.total_rows,), **f32)
+        d, dp = self.d, self.dp
+
+        def padded(w, rows, cols):
+            out = torch.zeros((rows, cols))
+            out[:w.shape[0], :w.shape[1]] = w
+            return out
+
+        self.Wc = [_Dense(padded(torch.randn((d, d), generator=gen) / math.sqrt(d) * 0.5, dp, dp), self.device, True)
+                   for _ in range(self.n_cross)]
+        self.bc = [_Dense(padded(torch.randn((1, d), generator=gen) * 0.05, 1, dp).view(-1), self.device, False)
+                   for _ in range(self.n_cross)]
+        widths = [d] + self.mlp
+        wpad = [dp] + self.mlp
+        self.Wm = [_Dense(padded(torch.randn((widths[i + 1], widths[i]), generator=gen) * math.sqrt(2.0 / widths[i]),
+                                 wpad[i + 1], wpad[i]), self.device, True) for i in range(len(self.mlp))]
+        self.bm = [_Dense(torch.randn((widths[i + 1],), generator=gen) * 0.05, self.device, False)
+                   for i in range(len(self.mlp))]
+        # output layer: w[K] and the bias in one buffer so that one reduction covers both
+        K = self.mlp[-1]
+        wb = torch.zeros(K + 4)
+        wb[:K] = torch.randn((K,), generator=gen) / math.sqrt(K)
+        self.out = _Dense(wb, self.device, False)
+        self.sched = torch.tensor([0.0, 1.0, 1.0, 0.0], **f32)
+        self.err = ops.new_error_word(self.device)
+        self.steps = 0
+        self._B = None
+
+    # -- parameters ---------------------------------------------------------------------------
+    def dense_params(self):
+        """name -> _Dense, names as in the test oracle."""
+        out = {}
+        for l in range(self.n_cross):
+            out['cross%d/W' % l], out['cross%d/b' % l] = self.Wc[l], self.bc[l]
+        for i in range(len(self.mlp)):
+            out['mlp%d/W' % i], out['mlp%d/b' % i] = self.Wm[i], self.bm[i]
+        out['out/wb'] = self.out
+        return out
+
+    def load_state(self, st):
+        """Copy parameters from an object with the test oracle's fields (unpadded numpy arrays)."""
+        d = self.d
+        self.V.copy_(torch.from_numpy(st.V))
+        for l in range(self.n_cross):
+            self.Wc[l].w.zero_()
+            self.Wc[l].w[:d, :d] = torch.from_numpy(st.Wc[l]).to(self.device)
+            self.bc[l].w.zero_()
+            self.bc[l].w[:d] = torch.from_numpy(st.bc[l]).to(self.device)
+        for i in range(len(self.mlp)):
+            W = torch.from_numpy(st.Wm[i]).to(self.device)
+            self.Wm[i].w.zero_()
+            self.Wm[i].w[:, :W.shape[1]] = W
+            self.bm[i].w.copy_(torch.from_numpy(st.bm[i]))
+        K = self.mlp[-1]
+        self.out.w.zero_()
+        self.out.w[:K] = torch.from_numpy(st.w_out).to(self.device)
+        self.out.w[K] = float(st.b_out[0])
+        for p in self.Wc + self.Wm:
+            ops.cast_bf16(p.w, p.h)
+
+    # -- buffers ------------------------------------------------------------------------------
+    def _splits(self, n_out, k_in, B):
+        """K-slices for a dW contraction [n_out, k_in] over the batch: enough workgroups to fill the
+        chip, each slice a whole number of 64-sample tiles."""
+        tiles = -(-n_out // 128) * -(-k_in // 128)
+        t64 = B // 64
+        s = max(1, min(512 // max(tiles, 1), t64))
+        while s > 1 and -(-t64 // -(-t64 // s)) != s:
+            s -= 1
+        return s
+
+    def _buffers(self, B, ids):
+        if self._B == (B, ids.dtype):
+            return
+        if B % 64:
+            raise ops.MiError("DCNv2: batch size must be a multiple of 64 (the contraction tile depth)")
+        dev, dp = self.device, self.dp
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.x = [torch.zeros((B, dp), **bf) for _ in range(self.n_cross + 1)]
+        self.u = [torch.empty((B, dp), **bf) for _ in range(self.n_cross)]
+        self.h = [torch.empty((B, w), **bf) for w in self.mlp]
+        self.dz = [torch.empty((B, w), **bf) for w in self.mlp]
+        self.dx = [torch.empty((B, dp), **bf) for _ in range(2)]
+        self.du = [torch.empty((B, dp), **bf) for _ in range(2)]
+        self.dx0 = torch.empty((B, dp), **f32)
+        self.logit, self.loss_rows, self.g = (torch.empty((B,), **f32) for _ in range(3))
+        self.loss = torch.empty((1,), **f32)
+        shapes = [(dp, dp)] * self.n_cross + [tuple(p.w.shape) for p in self.Wm]
+        self.split = {s: self._splits(s[0], s[1], B) for s in set(shapes)}
+        self.vec_slices = max(1, min(256, B // 64))
+        widest = max([dp] + self.mlp + [self.mlp[-1] + 4])
+        n_slab = max(max(self.split[s] * s[0] * s[1] for s in shapes), self.vec_slices * widest)
+        self.slab = torch.empty((n_slab,), **f32)
+        self.plan = ops.SortedPlan(self.toffs, self.T, self.total_rows, ids, bag_len=1, runs=False)
+        self._B = (B, ids.dtype)
+
+    # -- forward ------------------------------------------------------------------------------
+    def forward(self, ids, dense, labels=None):
+        """logits [B] (fp32); with labels also the loss rows and dL/dlogit of the mean BCE loss."""
+        B = ids.shape[0]
+        self._buffers(B, ids)
+        x0 = self.x[0]
+        ops.embag_fwd(self.V, self.toffs, self.T, ids, bag_len=1, out=x0, out_ld=self.dp, err=self.err)
+        ops.pack_dense_bf16(dense if self.n_dense else None, x0, self.T * self.dim, self.dp)
+        for l in range(self.n_cross):
+            ops.gemm_bf16(self.x[l], self.Wc[l].h, ops.MI_EPI_CROSS_FWD, out=self.x[l + 1], out1=self.u[l],
+                          bias=self.bc[l].w, in0=x0, in1=self.x[l])
+        a = self.x[-1]
+        for i in range(len(self.mlp)):
+            ops.gemm_bf16(a, self.Wm[i].h, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=self.h[i],
+                          bias=self.bm[i].w)
+            a = self.h[i]
+        K = self.mlp[-1]
+        ops.head_fwd(a, self.out.w[:K], self.out.w[K:K + 1], labels, 1.0 / B, self.logit,
+                     self.loss_rows if labels is not None else None, self.g if labels is not None else None)
+        return self.logit
+
+    # -- one training step --------------------------------------------------------------------
+    def _apply(self, p, n_slabs, n, stride):
+        ops.slab_adam(self.slab, n_slabs, n, stride, p.w, p.m, p.v, self.beta1, self.beta2, self.eps,
+                      lr_dev=self.sched, w_bf16=p.h, grad_out=p.grad if self.keep_grads else None)
+
+    def _weight_step(self, p, dY, X):
+        """dW = dY^T X as split-K slabs, then the fused reduction + Adam + bf16 re-cast."""
+        n_out, k_in = p.w.shape
+        s = self.split[(n_out, k_in)]
+        ops.gemm_bf16(dY, X, ops.MI_EPI_SLAB, a_rm=True, b_rm=True, M=n_out, N=k_in, K=dY.shape[0], k_splits=s,
+                      out=self.slab[:s * n_out * k_in].view(s, n_out, k_in))
+        self._apply(p, s, n_out * k_in, n_out * k_in)
+
+    def _bias_step(self, p, dY):
+        n = p.w.numel()
+        part = self.slab[:self.vec_slices * n].view(self.vec_slices, n)
+        ops.colsum_bf16(dY, self.vec_slices, part, N=n)
+        self._apply(p, self.vec_slices, n, n)
+
+    def train_step(self, ids, dense, labels, check_ids=False):
+        """Forward, backward and every optimizer update; returns the mean loss (1-element tensor)."""
+        B = ids.shape[0]
+        self.forward(ids, dense, labels)
+        ops.reduce_sum(self.loss_rows, 1.0 / B, out=self.loss)
+        ops.adam_schedule_step(self.sched, self.lr, self.beta1, self.beta2)
+        x0 = self.x[0]
+        n_mlp = len(self.mlp)
+        K = self.mlp[-1]
+        # output layer: dz of the last hidden layer, and the gradient of w and the bias
+        part = self.slab[:self.vec_slices * (K + 4)].view(self.vec_slices, K + 4)
+        part.zero_()
+        ops.head_bwd(self.g, self.out.w[:K], self.h[-1], self.dz[-1], self.vec_slices, part)
+        self._apply(self.out, self.vec_slices, K + 4, K + 4)
+        # MLP, last layer first.  Per layer: the data gradient with the OLD weights, then the weight step.
+        for i in reversed(range(n_mlp)):
+            dz = self.dz[i]
+            inp = self.h[i - 1] if i > 0 else self.x[-1]
+            if i > 0:
+                ops.gemm_bf16(dz, self.Wm[i].h, ops.MI_EPI_MASK, b_rm=True, out=self.dz[i - 1], in0=self.h[i - 1])
+            else:
+                # into the cross network: dx_L, du_{L-1} = dx_L * x0 and d x0 = dx_L * u_{L-1}
+                L = self.n_cross
+                if L:
+                    ops.gemm_bf16(dz, self.Wm[0].h, ops.MI_EPI_CROSS_BWD, b_rm=True, flags=ops.MI_EPI_INIT,
+                                  out=self.dx[L & 1], out1=self.du[L & 1], in0=x0, in2=self.u[L - 1], facc=self.dx0)
+                else:
+                    self.dx0.zero_()
+                    ops.gemm_bf16(dz, self.Wm[0].h, ops.MI_EPI_CROSS_BWD, b_rm=True, facc=self.dx0)
+            self._weight_step(self.Wm[i], dz, inp)
+            self._bias_step(self.bm[i], dz)
+        # cross layers, last first
+        for l in reversed(range(self.n_cross)):
+            du, dxn = self.du[(l + 1) & 1], self.dx[(l + 1) & 1]
+            if l > 0:
+                ops.gemm_bf16(du, self.Wc[l].h, ops.MI_EPI_CROSS_BWD, b_rm=True, out=self.dx[l & 1], in1=dxn,
+                              out1=self.du[l & 1], in0=x0, in2=self.u[l - 1], facc=self.dx0)
+            else:
+                ops.gemm_bf16(du, self.Wc[0].h, ops.MI_EPI_CROSS_BWD, b_rm=True, in1=dxn, facc=self.dx0)
+            self._weight_step(self.Wc[l], du, self.x[l])
+            self._bias_step(self.bc[l], du)
+        # embeddings: sort by row, sum each row's gradients in a fixed order, row-wise Adagrad
+        self.plan.prepare(ids)
+        ops.bwd_apply_adagrad_rowwise(self.plan, self.dx0, self.V, self.V_acc, self.emb_lr, self.emb_eps,
+                                      grad_ld=self.dp)
+        self.steps += 1
+        if check_ids:
+            ops.check_error_word(self.err, "DCN ids")
+        return self.loss
+
+    # -- accounting ---------------------------------------------------------------------------
+    def flops_per_sample(self):
+        """Multiply-adds x2 of the contractions of one training step (forward + both backward products)."""
+        fwd = self.n_cross * self.dp * self.dp
+        w = [self.dp] + self.mlp
+        fwd += sum(w[i] * w[i + 1] for i in range(len(self.mlp)))
+        return 3 * 2 * fwd

@@ -511,3 +511,33 @@ def gemm_bf16(A, B, mode, M=None, N=None, K=None, a_rm=False, b_rm=False, k_spli
     _lib.call('mi_gemm_bf16', int(a_rm), int(b_rm), M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), k_splits,
               ctypes.byref(e), _stream())
     return out
+
+
+def pack_dense_bf16(dense, x, col0, d_pad):
+    nd = dense.shape[1] if dense is not None else 0
+    _lib.call('mi_pack_dense_bf16', _p(dense), nd, x.shape[0], _p(x), x.stride(0), col0, d_pad, _stream())
+
+
+def colsum_bf16(X, slices, partial, N=None):
+    _lib.call('mi_colsum_bf16', _p(X), X.stride(0), X.shape[0], N or X.shape[1], slices, _p(partial),
+              partial.stride(0), _stream())
+
+
+def slab_adam(slab, n_slabs, n, slab_stride, w, m, v, beta1, beta2, eps, lr_t=0.0, lr_dev=None, w_bf16=None,
+              grad_out=None):
+    _lib.call('mi_slab_adam', _p(slab), n_slabs, n, slab_stride, _p(w), _p(m), _p(v), lr_t, _p(lr_dev), beta1, beta2,
+              eps, _p(w_bf16), _p(grad_out), _stream())
+
+
+def head_fwd(h, w, bias, labels, gscale, logit, loss_rows, g):
+    _lib.call('mi_head_fwd', _p(h), h.stride(0), h.shape[1], _p(w), _p(bias), _p(labels), gscale, h.shape[0],
+              _p(logit), _p(loss_rows), _p(g), _stream())
+
+
+def head_bwd(g, w, h, dh, slices, partial):
+    _lib.call('mi_head_bwd', _p(g), _p(w), _p(h), h.stride(0), h.shape[1], h.shape[0], _p(dh), dh.stride(0), slices,
+              _p(partial), partial.stride(0), _stream())
+
+
+def cast_bf16(src, dst):
+    _lib.call('mi_cast_bf16', _p(src), src.numel(), _p(dst), _stream())

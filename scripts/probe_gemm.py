@@ -1,7 +1,8 @@
 """Time the bf16 MFMA contraction on the shapes a DCN-v2 step uses (B = 65536)."""
 import sys
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recommendation_amd import ops
 
 dev = torch.device('cuda:0')
