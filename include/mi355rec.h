@@ -414,6 +414,44 @@ int mi_head_bwd(const float* g, const float* w, const void* h, int64_t ld_h, int
 /* out (bf16) = in (fp32). */
 int mi_cast_bf16(const float* in, int64_t n, void* out, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * DIN local activation unit (not in the reference; its nearest analogue is the 6-id bag with
+ * uniform weights, r_model.py:68-80).  A sample has a history of up to L item ids hist[B][L]
+ * (len[b] of them live), and a candidate item qid[b]; all ids index ONE table E[rows][dim],
+ * dim = 64.  Each live history item k_j gets the weight
+ *   a_j = MLP([q, k_j, q-k_j, q*k_j])     4*dim -> h1 -> h2 -> 1, ReLU on the hidden layers
+ * and pooled[b] = sum_j a_j k_j (no softmax).  The MLP is run by the caller over all B*L rows
+ * of A with mi_gemm_bf16 (two wide layers) and mi_head_fwd (the 1-wide one); its backward with
+ * mi_head_bwd / mi_gemm_bf16; these entry points do the memory-bound rest.
+ * ---------------------------------------------------------------------------------- */
+
+/* Gather + build: A[B*L][4*dim] bf16 rows [q | k | q-k | q*k] (zero rows for positions
+ * j >= len[b], negative ids, and ids >= rows - the latter also set MI_IDERR_RANGE), and
+ * ids_all[B][L+1] int32 = the live history ids (else -1) followed by the candidate id: the index
+ * list of the sparse backward.  q_out (optional) receives the fp32 candidate rows. */
+int mi_din_lau_build(const float* E, int64_t rows, int dim, const void* hist, const void* qid,
+                     int idx_bits, const int32_t* len, int64_t B, int L, void* A, int32_t* ids_all,
+                     float* q_out, int64_t ld_q, int32_t* err, void* stream);
+
+/* pooled[b][0..dim) = sum over live j (ascending) of a[b*L+j] * k_j, k_j taken from A. */
+int mi_din_lau_pool(const void* A, const float* a, const int32_t* ids_all, int64_t B, int L, int dim,
+                    float* pooled, int64_t ld, void* stream);
+
+/* da[b*L+j] = <dpooled[b], k_j> on live positions, 0 elsewhere. */
+int mi_din_lau_pool_bwd(const void* A, const float* dpooled, int64_t ld, const int32_t* ids_all,
+                        int64_t B, int L, int dim, float* da, void* stream);
+
+/* dA[B*L][4*dim] (bf16) = gradient of the MLP's input rows.  Writes dE[B][L+1][dim] fp32, laid
+ * out like ids_all:  d k_j = a_j*dpooled + dA_k - dA_d + q*dA_p;  d q = dq_extra (optional, what
+ * the layers above send to q directly) + sum_j (dA_q + dA_d + k_j*dA_p), j ascending. */
+int mi_din_lau_scatter(const void* A, const void* dA, const float* a, const float* dpooled,
+                       int64_t ld_dp, const float* dq_extra, int64_t ld_dq, const int32_t* ids_all,
+                       int64_t B, int L, int dim, float* dE, void* stream);
+
+/* BCE-with-logits on fp32 logits: loss rows and g = (sigmoid(z) - y) * gscale (either may be NULL). */
+int mi_bce_logits(const float* logits, const float* labels, int64_t B, float gscale,
+                  float* loss_rows, float* g, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

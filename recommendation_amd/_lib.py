@@ -88,6 +88,11 @@ _SIGNATURES = {
     'mi_head_fwd': (c_int, [P, c_int64, c_int, P, P, P, c_float, c_int64, P, P, P, P]),
     'mi_head_bwd': (c_int, [P, P, P, c_int64, c_int, c_int64, P, c_int64, c_int, P, c_int64, P]),
     'mi_cast_bf16': (c_int, [P, c_int64, P, P]),
+    'mi_din_lau_build': (c_int, [P, c_int64, c_int, P, P, c_int, P, c_int64, c_int, P, P, P, c_int64, P, P]),
+    'mi_din_lau_pool': (c_int, [P, P, P, c_int64, c_int, c_int, P, c_int64, P]),
+    'mi_din_lau_pool_bwd': (c_int, [P, P, c_int64, P, c_int64, c_int, c_int, P, P]),
+    'mi_din_lau_scatter': (c_int, [P, P, P, P, c_int64, P, c_int64, P, c_int64, c_int, c_int, P, P]),
+    'mi_bce_logits': (c_int, [P, P, c_int64, c_float, P, P, P]),
     'mi_shard_block_ints': (c_int64, [c_int64, c_int]),
     'mi_shard_route': (c_int, [P, c_int, P, c_int, c_int64, c_int, P, P, P]),
     'mi_fm_partial_fwd': (c_int, [POINTER(FmTable), c_int64, P, c_int, c_int64, c_int, P, P, P, P, P, P]),

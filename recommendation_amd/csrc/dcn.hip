@@ -20,21 +20,65 @@ __global__ __launch_bounds__(256) void pack_dense_kernel(const float* __restrict
   x[b * ld + col0 + j] = j < nd ? mi_f2bf(dense[b * nd + j]) : (unsigned short) 0;
 }
 
-// partial[s][n] = sum over rows of slice s of X[m][n]; thread per 4 columns, fixed row order
+// partial[s][n] = sum over rows of slice s of X[m][n].  Block = 64 column threads (8 columns each)
+// x 4 row lanes; a row lane walks rows lo+ty, lo+ty+4, ... with four loads in flight, the four
+// lanes are then added in lane order: a fixed order for a given (M, slices).
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* __restrict__ X, int64_t ld, int64_t M,
                                                          int N, int rows_per_slice, float* __restrict__ partial,
                                                          int64_t ld_partial) {
-  const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (n >= N) return;
+  __shared__ float sh[3][64][8];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = (blockIdx.x * 64 + tx) * 8;
   const int s = blockIdx.y;
   const int64_t lo = (int64_t) s * rows_per_slice;
   const int64_t hi = lo + rows_per_slice < M ? lo + rows_per_slice : M;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t m = lo; m < hi; ++m) {
-    const ushort4 u = *reinterpret_cast<const ushort4*>(X + m * ld + n);
-    acc.x += mi_bf2f(u.x); acc.y += mi_bf2f(u.y); acc.z += mi_bf2f(u.z); acc.w += mi_bf2f(u.w);
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  if (n < N) {
+    const bool wide = n + 8 <= N;  // N % 4 == 0: the last thread of a row may own only 4 columns
+    int64_t m = lo + ty;
+    for (; m + 12 < hi; m += 16) {
+      uint4 u[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned short* p = X + (m + 4 * j) * ld + n;
+        if (wide) u[j] = *reinterpret_cast<const uint4*>(p);
+        else { const uint2 h = *reinterpret_cast<const uint2*>(p); u[j] = make_uint4(h.x, h.y, 0u, 0u); }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0] += __uint_as_float(u[j].x << 16); acc[1] += __uint_as_float(u[j].x & 0xFFFF0000u);
+        acc[2] += __uint_as_float(u[j].y << 16); acc[3] += __uint_as_float(u[j].y & 0xFFFF0000u);
+        acc[4] += __uint_as_float(u[j].z << 16); acc[5] += __uint_as_float(u[j].z & 0xFFFF0000u);
+        acc[6] += __uint_as_float(u[j].w << 16); acc[7] += __uint_as_float(u[j].w & 0xFFFF0000u);
+      }
+    }
+    for (; m < hi; m += 4) {
+      const unsigned short* p = X + m * ld + n;
+      uint4 u;
+      if (wide) u = *reinterpret_cast<const uint4*>(p);
+      else { const uint2 h = *reinterpret_cast<const uint2*>(p); u = make_uint4(h.x, h.y, 0u, 0u); }
+      acc[0] += __uint_as_float(u.x << 16); acc[1] += __uint_as_float(u.x & 0xFFFF0000u);
+      acc[2] += __uint_as_float(u.y << 16); acc[3] += __uint_as_float(u.y & 0xFFFF0000u);
+      acc[4] += __uint_as_float(u.z << 16); acc[5] += __uint_as_float(u.z & 0xFFFF0000u);
+      acc[6] += __uint_as_float(u.w << 16); acc[7] += __uint_as_float(u.w & 0xFFFF0000u);
+    }
   }
-  *reinterpret_cast<float4*>(partial + (int64_t) s * ld_partial + n) = acc;
+  if (ty > 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[ty - 1][tx][k] = acc[k];
+  }
+  __syncthreads();
+  if (ty == 0 && n < N) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += sh[t][tx][k];
+    float* out = partial + (int64_t) s * ld_partial + n;
+    *reinterpret_cast<float4*>(out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (n + 8 <= N) *reinterpret_cast<float4*>(out + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
 }
 
 // g = sum_s slab[s][i] (s ascending) -> TensorFlow-form Adam on the fp32 master -> bf16 copy
@@ -47,7 +91,15 @@ __global__ __launch_bounds__(256) void slab_adam_kernel(const float* __restrict_
   const int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = 0; s < S; ++s) {
+  int s = 0;
+  for (; s + 8 <= S; s += 8) {  // eight loads in flight, added in slab order
+    float4 p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = *reinterpret_cast<const float4*>(slab + (int64_t) (s + j) * slab_stride + i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { g.x += p[j].x; g.y += p[j].y; g.z += p[j].z; g.w += p[j].w; }
+  }
+  for (; s < S; ++s) {
     const float4 p = *reinterpret_cast<const float4*>(slab + (int64_t) s * slab_stride + i);
     g.x += p.x; g.y += p.y; g.z += p.z; g.w += p.w;
   }
@@ -184,8 +236,9 @@ extern "C" int mi_colsum_bf16(const void* X, int64_t ld, int64_t M, int N, int s
   MI_REQUIRE(X && partial && M >= 1 && N >= 4 && N % 4 == 0 && ld % 4 == 0 && a8(X) && a16(partial) &&
                  ld_partial % 4 == 0 && ld_partial >= N && slices >= 1 && slices <= 65535,
              "mi_colsum_bf16: bad arguments");
+  MI_REQUIRE(ld % 8 == 0 && ((uintptr_t) X & 15) == 0, "mi_colsum_bf16: rows must be 16-byte aligned");
   const int rps = (int) mi_cdiv(M, slices);
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned) mi_cdiv(N / 4, 256), (unsigned) slices), dim3(256), 0,
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned) mi_cdiv(N, 512), (unsigned) slices), dim3(256), 0,
                      (hipStream_t) stream, (const unsigned short*) X, ld, M, N, rps, partial, ld_partial);
   MI_LAUNCH_CHECK();
   return MI_OK;

@@ -541,3 +541,31 @@ def head_bwd(g, w, h, dh, slices, partial):
 
 def cast_bf16(src, dst):
     _lib.call('mi_cast_bf16', _p(src), src.numel(), _p(dst), _stream())
+
+
+# ----------------------------------------------------------------------------- DIN local activation unit
+def din_lau_build(E, hist, qid, lengths, A, ids_all, q_out=None, err=None):
+    B, L = hist.shape
+    _lib.call('mi_din_lau_build', _p(E), E.shape[0], E.shape[1], _p(hist), _p(qid), _idx_bits(hist), _p(lengths), B, L,
+              _p(A), _p(ids_all), _p(q_out), q_out.stride(0) if q_out is not None else 0, _p(err), _stream())
+
+
+def din_lau_pool(A, a, ids_all, dim, pooled):
+    B, L1 = ids_all.shape
+    _lib.call('mi_din_lau_pool', _p(A), _p(a), _p(ids_all), B, L1 - 1, dim, _p(pooled), pooled.stride(0), _stream())
+
+
+def din_lau_pool_bwd(A, dpooled, ids_all, dim, da):
+    B, L1 = ids_all.shape
+    _lib.call('mi_din_lau_pool_bwd', _p(A), _p(dpooled), dpooled.stride(0), _p(ids_all), B, L1 - 1, dim, _p(da),
+              _stream())
+
+
+def din_lau_scatter(A, dA, a, dpooled, dq_extra, ids_all, dim, dE):
+    B, L1 = ids_all.shape
+    _lib.call('mi_din_lau_scatter', _p(A), _p(dA), _p(a), _p(dpooled), dpooled.stride(0), _p(dq_extra),
+              dq_extra.stride(0) if dq_extra is not None else 0, _p(ids_all), B, L1 - 1, dim, _p(dE), _stream())
+
+
+def bce_logits(logits, labels, gscale, loss_rows, g):
+    _lib.call('mi_bce_logits', _p(logits), _p(labels), logits.numel(), gscale, _p(loss_rows), _p(g), _stream())
