@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument('--cpu-steps', type=int, default=20)
     ap.add_argument('--stage-reps', type=int, default=50)
     ap.add_argument('--no-graph', action='store_true', help='launch the step eagerly instead of replaying a HIP graph')
+    ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din'],
+                    help='fm (default, the headline configuration); dcn / din: the bf16 matrix-core configurations, 1 GPU')
     return ap.parse_args()
 
 
@@ -157,8 +159,148 @@ def cpu_baseline(args, rows, fm, batches):
                        % (n, args.batch, len(rows), args.dim, os.cpu_count() or 0))
 
 
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 peak of MI355X (MI355X_MICROARCH; the 5 PF headline includes 2:1 sparsity)
+
+
+def _timed_steps(step, args):
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def _line(args, workload, B, dt, dtype, config):
+    return {'metric': 'train_samples_per_sec', 'value': round(B * args.steps / dt, 1), 'unit': 'samples/s', 'n_gpus': 1,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+            'config': dict(workload=workload, global_batch=B, launch='eager', parallelism='single', **config)}
+
+
+def bench_dcn(args):
+    """DCN-v2 (3 cross layers + MLP 1024-1024-512-1) on the Criteo shape, batch 65536 unless --batch is given."""
+    from recommendation_amd import ops
+    from recommendation_amd.dcn import DCNv2
+    dev = torch.device('cuda', 0)
+    B = args.batch if args.batch != 8192 else 65536
+    rows = CRITEO_KAGGLE
+    m = DCNv2(rows, 16, 13, dev)
+    batches = gen_batches(4, B, rows, 13, args.dist, args.idx_bits, dev, seed=1000)
+    it = [0]
+
+    def step():
+        m.train_step(*batches[it[0] % len(batches)])
+        it[0] += 1
+
+    dt = _timed_steps(step, args)
+    ops.check_error_word(m.err, "bench ids")
+    res = _line(args, 'dcn_v2_criteo_26x16_b%d' % B, B, dt, 'bf16',
+                dict(tables=len(rows), total_rows=int(sum(rows)), dim=16, n_dense=13, d_padded=m.dp, cross_layers=3,
+                     mlp=[1024, 1024, 512, 1], accumulate='f32', optimizer='adam_tf (dense) + adagrad_rowwise (tables)'))
+    res['step_tflops'] = round(m.flops_per_sample() * B * args.steps / dt / 1e12, 1)
+    # dominant kernel: the contraction.  Timed on the largest one of the step (the 1024x1024 MLP layer).
+    X, W, out = m.h[0], m.Wm[1].h, m.h[1]
+    ms = time_stage(lambda: ops.gemm_bf16(X, W, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=out, bias=m.bm[1].w),
+                    args.stage_reps)
+    flops = 2.0 * B * W.shape[0] * W.shape[1]
+    res['roofline'] = {'kernel': 'gemm_bf16_kernel (MLP layer %dx%d forward, M=%d)' % (W.shape[0], W.shape[1], B),
+                       'bound': 'mfma', 'achieved': round(flops / ms / 1e9, 1), 'peak': MFMA_PEAK_TFLOPS,
+                       'unit': 'TFLOP/s', 'frac': round(flops / ms / 1e9 / MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                       'alg_flops_per_launch': flops, 'ms_per_launch': round(ms, 5)}
+    if not args.no_cpu_baseline:
+        from oracle import dcn as odcn
+        Bc = 4096
+        st = odcn.State([8] * len(rows), 16, 13, seed=0)          # small tables, then the model's own weights
+        st.toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+        st.V = m.V.cpu().numpy()
+        st.acc = np.zeros(st.V.shape[0], np.float32)
+        ids, dense, labels = (t[:Bc].cpu().numpy() for t in batches[0])
+        odcn.train_step(st, ids, dense, labels, dtype=np.float32)
+        t0, n = time.perf_counter(), 0
+        while n < args.cpu_steps and time.perf_counter() - t0 < 20.0:
+            odcn.train_step(st, ids, dense, labels, dtype=np.float32)
+            n += 1
+        cdt = time.perf_counter() - t0
+        res['cpu_baseline'] = dict(value=round(n * Bc / cdt, 1), unit='samples/s',
+                                   cores=int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1)), kind='port',
+                                   sample='%d steps of batch %d (same model, fp32) through the numpy oracle; its '
+                                          'matrix products run on the BLAS threads numpy was given' % (n, Bc))
+    return res
+
+
+def bench_din(args):
+    """DIN local activation unit (1 M items x dim 64, history 100, lengths U[1,100], MLP 256-80-40-1), batch 8192."""
+    from recommendation_amd import ops
+    from recommendation_amd.din import DIN
+    dev = torch.device('cuda', 0)
+    B, L, rows = args.batch, 100, 1000000
+    m = DIN(rows, dev, max_len=L)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000)
+    batches = []
+    for _ in range(4):
+        hist = torch.randint(0, rows, (B, L), generator=g, device=dev)
+        if args.idx_bits == 32:
+            hist = hist.to(torch.int32)
+        qid = torch.randint(0, rows, (B,), generator=g, device=dev).to(hist.dtype)
+        lens = torch.randint(1, L + 1, (B,), generator=g, device=dev).to(torch.int32)
+        labels = (torch.rand((B,), generator=g, device=dev) < 0.3).to(torch.float32)
+        batches.append((hist, qid, lens, labels))
+    it = [0]
+
+    def step():
+        m.train_step(*batches[it[0] % len(batches)])
+        it[0] += 1
+
+    dt = _timed_steps(step, args)
+    ops.check_error_word(m.err, "bench ids")
+    res = _line(args, 'din_lau_1Mx64_L%d_b%d' % (L, B), B, dt, 'bf16',
+                dict(items=rows, dim=64, history=L, lengths='U[1,%d]' % L, lau_mlp=[256, 80, 40, 1],
+                     hidden_padded=[m.h1p, m.h2p], accumulate='f32',
+                     optimizer='adam_tf (dense) + adagrad_rowwise (table)'))
+    res['step_tflops'] = round(m.flops_per_sample() * B * args.steps / dt / 1e12, 1)
+    # dominant HBM kernel: the gather that builds the unit's input rows
+    hist, qid, lens, labels = batches[0]
+    ms = time_stage(lambda: ops.din_lau_build(m.E, hist, qid, lens, m.A, m.ids_all, q_out=m.feat[:, 64:], err=m.err),
+                    args.stage_reps)
+    live = int(lens.sum().item())
+    ib = args.idx_bits // 8
+    nbytes = live * 64 * 4 + B * L * ib + B * L * 4 * 64 * 2 + B * (L + 1) * 4   # live rows + ids + A rows + index list
+    res['roofline'] = {'kernel': 'din_build_kernel (gather + [q|k|q-k|q*k] rows)', 'bound': 'hbm',
+                       'achieved': round(nbytes / ms / 1e6, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                       'frac': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), 'traffic': None,
+                       'alg_bytes_per_launch': nbytes, 'ms_per_launch': round(ms, 5)}
+    if not args.no_cpu_baseline:
+        from oracle import din as odin
+        Bc = 1024
+        st = odin.State(16, seed=0)
+        st.rows = rows
+        st.E = m.E.cpu().numpy()
+        st.acc = np.zeros(rows, np.float32)
+        hb, qb, lb, yb = (t[:Bc].cpu().numpy() for t in batches[0])
+        odin.train_step(st, hb, qb, lb, yb, dtype=np.float32)
+        t0, n = time.perf_counter(), 0
+        while n < args.cpu_steps and time.perf_counter() - t0 < 20.0:
+            odin.train_step(st, hb, qb, lb, yb, dtype=np.float32)
+            n += 1
+        cdt = time.perf_counter() - t0
+        res['cpu_baseline'] = dict(value=round(n * Bc / cdt, 1), unit='samples/s',
+                                   cores=int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1)), kind='port',
+                                   sample='%d steps of batch %d (same model, fp32) through the numpy oracle' % (n, Bc))
+    return res
+
+
 def main():
     args = parse_args()
+    if args.workload != 'fm':
+        if args.gpus != 1 or int(os.environ.get('WORLD_SIZE', '1')) != 1:
+            raise SystemExit("--workload %s is a single-GPU configuration" % args.workload)
+        torch.cuda.set_device(0)
+        print(json.dumps(bench_dcn(args) if args.workload == 'dcn' else bench_din(args)))
+        return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -126,24 +126,27 @@ __global__ __launch_bounds__(256) void slab_adam_kernel(const float* __restrict_
   }
 }
 
-// Output layer, one wave per sample: logit = h . w + bias; BCE-with-logits loss row; g = dL/dlogit.
+// Output layer: logit = h . w + bias; BCE-with-logits loss row; g = dL/dlogit.  A group of `lpr`
+// lanes (a power of two <= 64, 4 columns per lane and pass) per sample.
 __global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned short* __restrict__ h, int64_t ld, int K,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                       const float* __restrict__ labels, float gscale, int64_t B,
-                                                      float* __restrict__ logit, float* __restrict__ loss_rows,
-                                                      float* __restrict__ g) {
-  const int64_t b = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= B) return;
-  const int lane = threadIdx.x & 63;
+                                                      int lpr, float* __restrict__ logit,
+                                                      float* __restrict__ loss_rows, float* __restrict__ g) {
+  const int per_block = 256 / lpr;
+  const int64_t b = (int64_t) blockIdx.x * per_block + threadIdx.x / lpr;
+  const int lane = threadIdx.x % lpr;
   float acc = 0.f;
-  for (int k = lane * 4; k < K; k += 256) {
-    const ushort4 u = *reinterpret_cast<const ushort4*>(h + b * ld + k);
-    const float4 ww = *reinterpret_cast<const float4*>(w + k);
-    acc = fmaf(mi_bf2f(u.x), ww.x, acc); acc = fmaf(mi_bf2f(u.y), ww.y, acc);
-    acc = fmaf(mi_bf2f(u.z), ww.z, acc); acc = fmaf(mi_bf2f(u.w), ww.w, acc);
+  if (b < B) {
+    for (int k = lane * 4; k < K; k += lpr * 4) {
+      const ushort4 u = *reinterpret_cast<const ushort4*>(h + b * ld + k);
+      const float4 ww = *reinterpret_cast<const float4*>(w + k);
+      acc = fmaf(mi_bf2f(u.x), ww.x, acc); acc = fmaf(mi_bf2f(u.y), ww.y, acc);
+      acc = fmaf(mi_bf2f(u.z), ww.z, acc); acc = fmaf(mi_bf2f(u.w), ww.w, acc);
+    }
   }
-  acc = mi_wave_sum(acc);
-  if (lane != 0) return;
+  for (int o = lpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane != 0 || b >= B) return;
   const float z = acc + (bias ? bias[0] : 0.f);
   if (logit) logit[b] = z;
   if (labels) {
@@ -175,31 +178,56 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   *reinterpret_cast<ushort4*>(dh + b * ld_dh + k) = o;
 }
 
-// partial[s][k] = sum over samples of slice s of g[b]*h[b][k] (k < K);  partial[s][K] = sum g[b]
+// partial[s][k] = sum over samples of slice s of g[b]*h[b][k] (k < K);  partial[s][K] = sum g[b].
+// Block = ct column threads (4 columns each; a power of two <= 64; the thread at k == K owns the
+// bias column) x 256/ct row lanes; a row lane walks rows lo+ty, lo+ty+rl, ...; lanes are then
+// added in lane order.
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ g,
                                                         const unsigned short* __restrict__ h, int64_t ld, int K,
-                                                        int64_t B, int rows_per_slice, float* __restrict__ partial,
-                                                        int64_t ld_partial) {
-  const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (k >= K + 4) return;
+                                                        int64_t B, int rows_per_slice, int ct,
+                                                        float* __restrict__ partial, int64_t ld_partial) {
+  __shared__ float sh[256][4];
+  const int rl = 256 / ct;
+  const int tx = threadIdx.x % ct, ty = threadIdx.x / ct;
+  const int k = (blockIdx.x * ct + tx) * 4;
   const int s = blockIdx.y;
   const int64_t lo = (int64_t) s * rows_per_slice;
   const int64_t hi = lo + rows_per_slice < B ? lo + rows_per_slice : B;
-  float* out = partial + (int64_t) s * ld_partial;
-  if (k >= K) {  // the bias column
-    float acc = 0.f;
-    for (int64_t b = lo; b < hi; ++b) acc += g[b];
-    out[K] = acc;
-    return;
-  }
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t b = lo; b < hi; ++b) {
-    const float gb = g[b];
-    const ushort4 u = *reinterpret_cast<const ushort4*>(h + b * ld + k);
-    acc.x = fmaf(gb, mi_bf2f(u.x), acc.x); acc.y = fmaf(gb, mi_bf2f(u.y), acc.y);
-    acc.z = fmaf(gb, mi_bf2f(u.z), acc.z); acc.w = fmaf(gb, mi_bf2f(u.w), acc.w);
+  if (k < K) {
+    int64_t b = lo + ty;
+    for (; b + 3 * (int64_t) rl < hi; b += 4 * (int64_t) rl) {
+      ushort4 u[4];
+      float gb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u[j] = *reinterpret_cast<const ushort4*>(h + (b + (int64_t) j * rl) * ld + k);
+        gb[j] = g[b + (int64_t) j * rl];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc.x = fmaf(gb[j], mi_bf2f(u[j].x), acc.x); acc.y = fmaf(gb[j], mi_bf2f(u[j].y), acc.y);
+        acc.z = fmaf(gb[j], mi_bf2f(u[j].z), acc.z); acc.w = fmaf(gb[j], mi_bf2f(u[j].w), acc.w);
+      }
+    }
+    for (; b < hi; b += rl) {
+      const float gb = g[b];
+      const ushort4 u = *reinterpret_cast<const ushort4*>(h + b * ld + k);
+      acc.x = fmaf(gb, mi_bf2f(u.x), acc.x); acc.y = fmaf(gb, mi_bf2f(u.y), acc.y);
+      acc.z = fmaf(gb, mi_bf2f(u.z), acc.z); acc.w = fmaf(gb, mi_bf2f(u.w), acc.w);
+    }
+  } else if (k == K) {
+    for (int64_t b = lo + ty; b < hi; b += rl) acc.x += g[b];
   }
-  *reinterpret_cast<float4*>(out + k) = acc;
+  sh[threadIdx.x][0] = acc.x; sh[threadIdx.x][1] = acc.y; sh[threadIdx.x][2] = acc.z; sh[threadIdx.x][3] = acc.w;
+  __syncthreads();
+  if (ty != 0 || k > K) return;
+  for (int t = 1; t < rl; ++t) {
+    acc.x += sh[t * ct + tx][0]; acc.y += sh[t * ct + tx][1]; acc.z += sh[t * ct + tx][2]; acc.w += sh[t * ct + tx][3];
+  }
+  float* out = partial + (int64_t) s * ld_partial;
+  if (k == K) out[K] = acc.x;
+  else *reinterpret_cast<float4*>(out + k) = acc;
 }
 
 // out (bf16) = in (fp32), n multiple of 4
@@ -261,8 +289,10 @@ extern "C" int mi_slab_adam(const float* slab, int n_slabs, int64_t n, int64_t s
 extern "C" int mi_head_fwd(const void* h, int64_t ld, int K, const float* w, const float* bias, const float* labels,
                            float gscale, int64_t B, float* logit, float* loss_rows, float* g, void* stream) {
   MI_REQUIRE(h && w && B >= 1 && K >= 4 && K % 4 == 0 && ld % 4 == 0 && a8(h) && a16(w), "mi_head_fwd: bad arguments");
-  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned) mi_cdiv(B, 4)), dim3(256), 0, (hipStream_t) stream,
-                     (const unsigned short*) h, ld, K, w, bias, labels, gscale, B, logit, loss_rows, g);
+  int lpr = 1;
+  while (lpr < 64 && lpr * 4 < K) lpr <<= 1;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned) mi_cdiv(B, 256 / lpr)), dim3(256), 0, (hipStream_t) stream,
+                     (const unsigned short*) h, ld, K, w, bias, labels, gscale, B, lpr, logit, loss_rows, g);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -277,8 +307,10 @@ extern "C" int mi_head_bwd(const float* g, const float* w, const void* h, int64_
   hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned) mi_cdiv(B * (K / 4), 256)), dim3(256), 0, s, g, w,
                      (const unsigned short*) h, ld_h, K, B, (unsigned short*) dh, ld_dh);
   const int rps = (int) mi_cdiv(B, slices);
-  hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned) mi_cdiv(K / 4 + 1, 256), (unsigned) slices), dim3(256), 0, s, g,
-                     (const unsigned short*) h, ld_h, K, B, rps, partial, ld_partial);
+  int ct = 1;
+  while (ct < 64 && ct < K / 4 + 1) ct <<= 1;
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned) mi_cdiv(K / 4 + 1, ct), (unsigned) slices), dim3(256), 0, s, g,
+                     (const unsigned short*) h, ld_h, K, B, rps, ct, partial, ld_partial);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -91,7 +91,7 @@ class DIN(object):
     def _splits(self, n_out, k_in, M):
         tiles = -(-n_out // 128) * -(-k_in // 128)
         t64 = M // 64
-        s = max(1, min(1024 // max(tiles, 1), t64))
+        s = max(1, min(512 // max(tiles, 1), t64))
         while s > 1 and -(-t64 // -(-t64 // s)) != s:
             s -= 1
         return s
