@@ -406,7 +406,8 @@ constexpr int GROUP_MAX = 16;  // a lane group sums runs up to this itself
 // WAVE_MAX go to the queue.  Every lane of the wave must call this together.
 template <int VEC, class Src, class Upd>
 __device__ __forceinline__ void wave_pending(const PlanDev& pl, const Src& src, const Upd& upd, int lanes,
-                                             bool pending, int beg, int end, uint32_t row, int token) {
+                                             bool pending, int beg, int end, uint32_t row, int token,
+                                             bool use_queue = true) {
   unsigned long long todo = __ballot(pending);
   while (todo) {  // uniform over the wave
     const int from = __ffsll((long long) todo) - 1;
@@ -416,8 +417,8 @@ __device__ __forceinline__ void wave_pending(const PlanDev& pl, const Src& src, 
     const uint32_t rr = (uint32_t) __shfl((int) row, from, 64);
     const int tk = __shfl(token, from, 64);
     if (re < 0) re = run_end_wave(pl.sorted_rows, pl.n, rb, rr);
-    if (re - rb > WAVE_MAX) {
-      if ((threadIdx.x & 63) == 0) queue_long(pl, tk);
+    if (re - rb > WAVE_MAX) {  // a workgroup's job: queued, or found by the long-run workgroups themselves
+      if (use_queue && (threadIdx.x & 63) == 0) queue_long(pl, tk);
       continue;
     }
     wave_run<VEC>(pl, src, upd, lanes, rb, re, rr);
@@ -459,19 +460,110 @@ __device__ __forceinline__ int kth_set_bit(unsigned long long m, int k) {
   return pos;
 }
 
-// Runs straight from sorted_rows (no run arrays in the plan): one WAVE per 64 consecutive sorted
-// entries.  Lane l holds entry l's row; a ballot of "row differs from the predecessor's" gives
-// the heads of the runs that start in this wave and, from the distance to the next head, their
-// lengths - one coalesced load instead of per-run probing.  The wave's 64/lanes lane groups
-// then take the heads 64/lanes at a time.  A run that continues past the wave's last entry, or
-// is longer than GROUP_MAX, is left to the whole wave (wave_pending).
+// One workgroup sums the run of `row` that starts at `beg` (end looked up unless given): its lane
+// groups stride over the entries and combine partial sums through a fixed LDS tree.  The order of
+// additions depends only on the run's length: reproducible bit for bit.  All threads call this.
 template <int VEC, class Src, class Upd>
-__global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src, Upd upd, int lanes) {
-  const int lane = threadIdx.x & 63;
-  const int base = (blockIdx.x * (UBLOCK / 64) + (threadIdx.x >> 6)) * 64;
-  if (base >= pl.n) return;  // uniform over the wave
+__device__ __forceinline__ void block_run(const PlanDev& pl, const Src& src, const Upd& upd, int lanes, int groups,
+                                          int beg, int end, uint32_t row, float* red, float* reds, int* sh_end) {
+  const int sub = threadIdx.x / lanes, c = threadIdx.x - sub * lanes;
+  const bool active = sub < groups;
+  int top = 1;
+  while (top < groups) top <<= 1;
+  if (end < 0) {
+    if (threadIdx.x < 64) {
+      const int e = run_end_wave(pl.sorted_rows, pl.n, beg, row);
+      if (threadIdx.x == 0) *sh_end = e;
+    }
+    __syncthreads();
+    end = *sh_end;
+  }
+  typename Upd::template Regs<VEC> regs;
+  if (sub == 0) upd.template load<VEC>((int64_t) row, c, regs);
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+  float sc = 0.f;
+  if (active) {
+    sum_run<VEC>(pl, src, c, beg + sub, end, groups, acc, sc);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[(sub * lanes + c) * VEC + k] = acc[k];
+    reds[sub * lanes + c] = sc;
+  }
+  __syncthreads();
+  for (int stride = top >> 1; stride >= 1; stride >>= 1) {
+    if (active && sub < stride && sub + stride < groups) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) red[(sub * lanes + c) * VEC + k] += red[((sub + stride) * lanes + c) * VEC + k];
+      reds[sub * lanes + c] += reds[(sub + stride) * lanes + c];
+    }
+    __syncthreads();
+  }
+  if (sub == 0) {
+    float g[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) g[k] = red[c * VEC + k];
+    upd.template finish<VEC>((int64_t) row, c, lanes, regs, g, reds[c]);
+  }
+  __syncthreads();
+}
+
+// Runs straight from sorted_rows (no run arrays in the plan), ONE launch for every run length.
+//
+// Workgroups [long_blocks, ...): one WAVE per 64 consecutive sorted entries.  Lane l holds entry
+// l's row; a ballot of "row differs from the predecessor's" gives the heads of the runs that
+// start in this wave and, from the distance to the next head, their lengths - one coalesced
+// load instead of per-run probing.  The wave's 64/lanes lane groups then take the heads 64/lanes
+// at a time.  A run that continues past the wave's last entry, or is longer than GROUP_MAX, is
+// left to the whole wave (wave_pending); one longer than WAVE_MAX is skipped here.
+//
+// Workgroups [0, long_blocks): each scans LONG_CHUNK entries for heads of runs longer than
+// WAVE_MAX (entry i heads one iff its row differs from entry i-1's and equals entry
+// i+WAVE_MAX's) and sums those with all its threads.  They are dispatched first and work beside
+// the short runs instead of after them; nothing is queued, no atomics on global memory.
+constexpr int LONG_CHUNK = 1024;
+constexpr int LONG_CAP = LONG_CHUNK / (WAVE_MAX + 1) + 2;  // heads of long runs are more than WAVE_MAX apart
+
+template <int VEC, class Src, class Upd>
+__global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src, Upd upd, int lanes, int groups,
+                                                           int long_blocks) {
   const uint32_t* keys = pl.sorted_rows;
   const uint32_t sentinel = pl.sentinel;
+  if ((int) blockIdx.x < long_blocks) {
+    __shared__ float red[UBLOCK * VEC];
+    __shared__ float reds[UBLOCK];
+    __shared__ int sh_end, sh_n, sh_heads[LONG_CAP];
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+    const int lo = blockIdx.x * LONG_CHUNK;
+    const int hi = lo + LONG_CHUNK < pl.n ? lo + LONG_CHUNK : pl.n;
+    for (int i = lo + threadIdx.x; i < hi; i += UBLOCK) {
+      if (i + WAVE_MAX >= pl.n) break;
+      const uint32_t key = keys[i];
+      if (key == sentinel || keys[i + WAVE_MAX] != key) continue;
+      if (i > 0 && keys[i - 1] == key) continue;
+      sh_heads[atomicAdd(&sh_n, 1)] = i;
+    }
+    __syncthreads();
+    const int nh = sh_n;
+    if (threadIdx.x == 0) {  // ascending position: the order a workgroup takes its runs in must not depend on timing
+      for (int x = 1; x < nh; ++x) {
+        const int v = sh_heads[x];
+        int y = x - 1;
+        for (; y >= 0 && sh_heads[y] > v; --y) sh_heads[y + 1] = sh_heads[y];
+        sh_heads[y + 1] = v;
+      }
+    }
+    __syncthreads();
+    for (int h = 0; h < nh; ++h) {
+      const int head = sh_heads[h];
+      block_run<VEC>(pl, src, upd, lanes, groups, head, -1, keys[head], red, reds, &sh_end);
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int base = ((blockIdx.x - long_blocks) * (UBLOCK / 64) + (threadIdx.x >> 6)) * 64;
+  if (base >= pl.n) return;  // uniform over the wave
   const int i = base + lane;
   const uint32_t key = i < pl.n ? keys[i] : sentinel;
   uint32_t edge = sentinel;  // lane 0: the row before the wave's first; lane 63: the row after its last
@@ -501,69 +593,25 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
       if (!open && len <= GROUP_MAX) group_run<VEC>(pl, src, upd, lanes, c, base + pos, len, row);
       else pending = (c == 0);
     }
-    wave_pending<VEC>(pl, src, upd, lanes, pending, base + pos, open ? -1 : base + endpos, row, base + pos);
+    wave_pending<VEC>(pl, src, upd, lanes, pending, base + pos, open ? -1 : base + endpos, row, base + pos, false);
   }
 }
 
 // Queued runs (longer than WAVE_MAX, or longer than 4 when lane groups straddle waves): one
-// workgroup per run strides over the entries and combines partial sums through a fixed LDS
-// tree.  The order of additions depends only on the run's length: reproducible bit for bit.
+// workgroup per run.
 template <int VEC, class Src, class Upd>
 __global__ __launch_bounds__(UBLOCK) void seg_queue_kernel(PlanDev pl, Src src, Upd upd, int lanes, int groups) {
   __shared__ float red[UBLOCK * VEC];
   __shared__ float reds[UBLOCK];
   __shared__ int sh_end;
-  const int sub = threadIdx.x / lanes, c = threadIdx.x - sub * lanes;
-  const bool active = sub < groups;
   const int n_q = pl.long_list[0];
-  int top = 1;
-  while (top < groups) top <<= 1;
   for (int i = blockIdx.x; i < n_q; i += gridDim.x) {
     const int token = pl.long_list[2 + i];
-    int beg, end;
-    uint32_t row;
-    if (pl.seg_offsets) {
-      beg = pl.seg_offsets[token];
-      end = pl.seg_offsets[token + 1];
-      row = pl.unique_rows[token];
-    } else {
-      beg = token;
-      row = pl.sorted_rows[token];
-      if (threadIdx.x < 64) {
-        const int e = run_end_wave(pl.sorted_rows, pl.n, beg, row);
-        if (threadIdx.x == 0) sh_end = e;
-      }
-      __syncthreads();
-      end = sh_end;
-    }
-    typename Upd::template Regs<VEC> regs;
-    if (sub == 0) upd.template load<VEC>((int64_t) row, c, regs);
-    float acc[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-    float sc = 0.f;
-    if (active) {
-      sum_run<VEC>(pl, src, c, beg + sub, end, groups, acc, sc);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) red[(sub * lanes + c) * VEC + k] = acc[k];
-      reds[sub * lanes + c] = sc;
-    }
-    __syncthreads();
-    for (int stride = top >> 1; stride >= 1; stride >>= 1) {
-      if (active && sub < stride && sub + stride < groups) {
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) red[(sub * lanes + c) * VEC + k] += red[((sub + stride) * lanes + c) * VEC + k];
-        reds[sub * lanes + c] += reds[(sub + stride) * lanes + c];
-      }
-      __syncthreads();
-    }
-    if (sub == 0) {
-      float g[VEC];
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) g[k] = red[c * VEC + k];
-      upd.template finish<VEC>((int64_t) row, c, lanes, regs, g, reds[c]);
-    }
-    __syncthreads();
+    if (pl.seg_offsets)
+      block_run<VEC>(pl, src, upd, lanes, groups, pl.seg_offsets[token], pl.seg_offsets[token + 1],
+                     pl.unique_rows[token], red, reds, &sh_end);
+    else
+      block_run<VEC>(pl, src, upd, lanes, groups, token, -1, pl.sorted_rows[token], red, reds, &sh_end);
   }
   // The workgroup that finishes last leaves the queue empty for the next call: every
   // workgroup read the count before taking its ticket, so nobody still needs it.
@@ -672,11 +720,16 @@ int run_segments(const mi_bwd_plan* plan, const PlanDev& pl, const Src& src, con
                    g.vec, g.lanes);
       return MI_ERR_UNSUPPORTED;
     }
-    const unsigned grid = (unsigned) mi_cdiv(plan->n_entries, UBLOCK);
+    const int long_blocks = (int) mi_cdiv(plan->n_entries, LONG_CHUNK);
+    const unsigned grid = (unsigned) (long_blocks + mi_cdiv(plan->n_entries, UBLOCK));
     if (g.vec == 4)
-      hipLaunchKernelGGL((seg_sorted_kernel<4, Src, Upd>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes);
+      hipLaunchKernelGGL((seg_sorted_kernel<4, Src, Upd>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes, g.gpb,
+                         long_blocks);
     else
-      hipLaunchKernelGGL((seg_sorted_kernel<1, Src, Upd>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes);
+      hipLaunchKernelGGL((seg_sorted_kernel<1, Src, Upd>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes, g.gpb,
+                         long_blocks);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
   }
   if (g.vec == 4)
     hipLaunchKernelGGL((seg_queue_kernel<4, Src, Upd>), dim3(LONG_GRID), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes,
