@@ -281,6 +281,28 @@ int mi_fm_dense_step(const float* g, const float* dense, int n_dense, int64_t B,
                      const float* lr_dev, float beta1, float beta2, float eps, float* loss_out,
                      void* stream);
 
+/* mi_fm_fwd, the per-table sort of mi_embag_bwd_prepare (the form without run arrays) and,
+ * when sched != NULL, mi_adam_schedule_step in ONE launch: the three need only the step's inputs,
+ * so the launch lasts as long as the longest of them.  B <= mi_fm_fwd_sort_max_batch() (a table's
+ * B entries are sorted in the LDS of one CU); sorted_rows[B*T], perm[B*T] as mi_embag_bwd_prepare
+ * writes them.  Results are bit-identical to the separate calls. */
+int mi_fm_fwd_sort_max_batch(void);
+int mi_fm_fwd_sort(const mi_fm_table* tab, const int64_t* table_offsets, int T, const void* ids,
+                   int idx_bits, int64_t B, const float* dense, int n_dense, const float* wd,
+                   const float* bias, const float* labels, float gscale, float* logit, float* S,
+                   float* loss_rows, float* g, int32_t* err, int64_t total_rows,
+                   uint32_t* sorted_rows, int32_t* perm, float* sched, float lr, float beta1,
+                   float beta2, void* stream);
+
+/* mi_fm_bwd_apply and mi_fm_dense_step in ONE launch (both start from g; neither needs the
+ * other).  lr / lr_dev belong to the sparse side (optimizer `opt`), dense_lr_t / dense_lr_dev
+ * to the dense side's Adam.  Results are bit-identical to the separate calls. */
+int mi_fm_bwd_apply_dense(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* g,
+                          const float* S, int opt, float lr, const float* lr_dev, float beta1,
+                          float beta2, float eps, const float* dense, int n_dense,
+                          const float* loss_rows, float* dp, float* dm, float* dv, float dense_lr_t,
+                          const float* dense_lr_dev, float* loss_out, void* stream);
+
 /* tf.train.AdamOptimizer's scalar state kept on the device, as TensorFlow keeps it
  * (model_trainer.py:157): sched = {alpha_t, beta1_power, beta2_power}, initialised by the
  * caller to {0, 1, 1}.  One call = one optimizer step: both powers are multiplied by their

@@ -93,6 +93,11 @@ _SIGNATURES = {
     'mi_din_lau_pool_bwd': (c_int, [P, P, c_int64, P, c_int64, c_int, c_int, P, P]),
     'mi_din_lau_scatter': (c_int, [P, P, P, P, c_int64, P, c_int64, P, c_int64, c_int, c_int, P, P]),
     'mi_bce_logits': (c_int, [P, P, c_int64, c_float, P, P, P]),
+    'mi_fm_fwd_sort_max_batch': (c_int, []),
+    'mi_fm_fwd_sort': (c_int, [POINTER(FmTable), P, c_int, P, c_int, c_int64, P, c_int, P, P, P, c_float, P, P, P, P,
+                               P, c_int64, P, P, P, c_float, c_float, c_float, P]),
+    'mi_fm_bwd_apply_dense': (c_int, [POINTER(BwdPlan), POINTER(FmTable), P, P, c_int, c_float, P, c_float, c_float,
+                                      c_float, P, c_int, P, P, P, P, c_float, P, P, P]),
     'mi_shard_block_ints': (c_int64, [c_int64, c_int]),
     'mi_shard_route': (c_int, [P, c_int, P, c_int, c_int64, c_int, P, P, P]),
     'mi_fm_partial_fwd': (c_int, [POINTER(FmTable), c_int64, P, c_int, c_int64, c_int, P, P, P, P, P, P]),

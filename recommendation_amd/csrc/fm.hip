@@ -21,167 +21,59 @@
 
 namespace {
 
+}  // namespace
+#include "fm_body.h"
+#include "table_sort.h"
+namespace {
+
 template <typename IDX, int DIM>
-__global__ __launch_bounds__(256) void fm_fwd_kernel(mi_fm_table tab, const int64_t* __restrict__ toffs, int T,
-                                                    const void* __restrict__ ids, int B,
-                                                    const float* __restrict__ dense, int n_dense,
-                                                    const float* __restrict__ wd, const float* __restrict__ bias,
-                                                    const float* __restrict__ labels, float gscale,
-                                                    float* __restrict__ logit, float* __restrict__ S,
-                                                    float* __restrict__ loss_rows, float* __restrict__ g,
-                                                    int32_t* __restrict__ err) {
-  constexpr int CH = DIM / 4;                // lanes across one row
-  constexpr int G = CH > 16 ? CH : 16;       // lanes per sample
-  constexpr int FP = G / CH;                 // fields in flight per sample
-  const int gid = blockIdx.x * (256 / G) + threadIdx.x / G;
-  if (gid >= B) return;
-  const int l = threadIdx.x % G;
-  const int c = l % CH;
-  const int q = l / CH;
-  const float* __restrict__ rec = tab.rec;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sq = s;
-  float lin = 0.f;
-  int bad = 0;
-  // Fields in batches of UF per lane: first every id of the batch, then every row, so the
-  // loads of a batch are all in flight together (two dependent round trips per batch, not
-  // two per field).  A slot past T or with a bad id reads row 0 and is masked out.
-  constexpr int UF = 8;
-  for (int f0 = q; f0 < T; f0 += FP * UF) {
-    int64_t row[UF];
-    bool ok[UF];
-#pragma unroll
-    for (int u = 0; u < UF; ++u) {
-      const int f = f0 + u * FP;
-      const bool present = f < T;
-      const int fs = present ? f : 0;
-      const int64_t id = mi_ld_id<IDX>(ids, (int64_t) gid * T + fs);
-      const int64_t base = toffs[fs];
-      const int64_t rows = toffs[fs + 1] - base;
-      ok[u] = present && id >= 0 && id < rows;  // FM has no padding id: every field carries one id
-      if (present && !ok[u]) bad |= MI_IDERR_RANGE;
-      row[u] = ok[u] ? base + id : 0;
-    }
-    float4 v[UF];
-    float w[UF];
-#pragma unroll
-    for (int u = 0; u < UF; ++u) {
-      const float* r = rec + row[u] * tab.stride;
-      v[u] = *reinterpret_cast<const float4*>(r + c * 4);
-      w[u] = (c == 0) ? r[tab.off_w1] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < UF; ++u) {
-      const float4 x = make_float4(ok[u] ? v[u].x : 0.f, ok[u] ? v[u].y : 0.f, ok[u] ? v[u].z : 0.f,
-                                   ok[u] ? v[u].w : 0.f);
-      lin += ok[u] ? w[u] : 0.f;
-      s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
-      sq.x = fmaf(x.x, x.x, sq.x); sq.y = fmaf(x.y, x.y, sq.y);
-      sq.z = fmaf(x.z, x.z, sq.z); sq.w = fmaf(x.w, x.w, sq.w);
-    }
-  }
-  // combine the field phases (lanes that own the same columns)
-#pragma unroll
-  for (int o = CH; o < G; o <<= 1) {
-    s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
-    s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
-    sq.x += __shfl_xor(sq.x, o, 64); sq.y += __shfl_xor(sq.y, o, 64);
-    sq.z += __shfl_xor(sq.z, o, 64); sq.w += __shfl_xor(sq.w, o, 64);
-  }
-  if (q == 0 && S) *reinterpret_cast<float4*>(S + (int64_t) gid * DIM + c * 4) = s;
-  float pair = (q == 0) ? 0.5f * ((s.x * s.x - sq.x) + (s.y * s.y - sq.y) + (s.z * s.z - sq.z) + (s.w * s.w - sq.w)) : 0.f;
-  for (int j = l; j < n_dense; j += G) lin = fmaf(wd[j], dense[(int64_t) gid * n_dense + j], lin);
-  float tot = pair + lin;
-#pragma unroll
-  for (int o = 1; o < G; o <<= 1) tot += __shfl_xor(tot, o, 64);
-#pragma unroll
-  for (int o = 1; o < G; o <<= 1) bad |= __shfl_xor(bad, o, 64);
-  if (l == 0) {
-    const float z = tot + (bias ? bias[0] : 0.f);
-    if (logit) logit[gid] = z;
-    if (labels) {
-      const float y = labels[gid];
-      const float az = fabsf(z);
-      const float e = expf(-az);
-      if (loss_rows) loss_rows[gid] = fmaxf(z, 0.f) - z * y + log1pf(e);
-      const float sig = z >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
-      if (g) g[gid] = (sig - y) * gscale;
-    }
-    if (bad && err) atomicOr(err, bad);
-  }
+__global__ __launch_bounds__(256) void fm_fwd_kernel(FmFwdArgs a) {
+  fm_fwd_body<IDX, DIM>(a, blockIdx.x, 256);
 }
 
-__device__ __forceinline__ float block_sum_1024(float acc, float* sh) {
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
-    if ((int) threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-    __syncthreads();
-  }
-  return sh[0];
-}
-
-// Workgroup j < n_dense: dwd[j] = sum_b g[b]*dense[b][j]; j == n_dense: dbias = sum_b g[b];
-// j == n_dense+1 (only when loss_rows != NULL): mean of the loss rows.  Fixed summation
-// order.  When dp != NULL the gradient is consumed in place by TensorFlow-form Adam on dp[j].
-// g, dense rows and loss rows are g_ld, dense_ld and loss_ld floats apart (1, n_dense, 1 for plain arrays).
-__global__ __launch_bounds__(1024) void fm_dense_kernel(const float* __restrict__ g, int64_t g_ld,
-                                                       const float* __restrict__ dense, int64_t dense_ld,
-                                                       int n_dense, int64_t B, float* __restrict__ grad_out,
-                                                       const float* __restrict__ loss_rows, int64_t loss_ld,
-                                                       float* __restrict__ dp,
-                                                       float* __restrict__ dm, float* __restrict__ dv, float lr_t,
-                                                       const float* __restrict__ lr_dev, float b1, float b2,
-                                                       float eps, float* __restrict__ loss_out) {
-  __shared__ float sh[1024];
-  const int j = blockIdx.x;
-  float acc = 0.f;
-  if (j < n_dense) {
-    for (int64_t b = threadIdx.x; b < B; b += 1024) acc = fmaf(g[b * g_ld], dense[b * dense_ld + j], acc);
-  } else if (j == n_dense) {
-    for (int64_t b = threadIdx.x; b < B; b += 1024) acc += g[b * g_ld];
-  } else {
-    for (int64_t b = threadIdx.x; b < B; b += 1024) acc += loss_rows[b * loss_ld];
-  }
-  const float tot = block_sum_1024(acc, sh);
-  if (threadIdx.x != 0) return;
-  if (j > n_dense) {
-    loss_out[0] = tot / (float) B;
+// One launch for everything of a step that needs only its inputs: workgroup t < T sorts table t's
+// (row, position) pairs in LDS, the others run the forward, and one thread advances the optimizer
+// schedule (its consumers run in later launches).  The two halves do not depend on each other, so
+// the launch lasts as long as the longer one instead of their sum.
+template <typename IDX, int DIM>
+__global__ __launch_bounds__(TS_THREADS) void fm_fwd_sort_kernel(FmFwdArgs a, int bag_len_one_n, uint32_t sentinel,
+                                                                uint32_t* __restrict__ sorted_rows,
+                                                                uint32_t* __restrict__ perm, float* __restrict__ sched,
+                                                                float lr, float b1, float b2) {
+  if ((int) blockIdx.x < a.T) {
+    table_sort_body<IDX>(blockIdx.x, a.toffs, a.T, a.ids, 1, bag_len_one_n, sentinel, sorted_rows, perm);
     return;
   }
-  if (grad_out) grad_out[j] = tot;
-  if (dp) {
-    const float mi = dm[j] + (tot - dm[j]) * (1.0f - b1);
-    const float vi = dv[j] + (tot * tot - dv[j]) * (1.0f - b2);
-    dm[j] = mi;
-    dv[j] = vi;
-    dp[j] -= (mi * (lr_dev ? lr_dev[0] : lr_t)) / (sqrtf(vi) + eps);
-  }
+  if (sched && (int) blockIdx.x == a.T && threadIdx.x == 0) adam_schedule_body(sched, lr, b1, b2);
+  fm_fwd_body<IDX, DIM>(a, blockIdx.x - a.T, TS_THREADS);
 }
 
-// sched = {alpha_t, beta1_power, beta2_power}: TensorFlow keeps the two powers as fp32 variables
-// on the device and multiplies them by beta once per step; alpha_t is formed from them in fp32.
+__global__ __launch_bounds__(FM_DENSE_THREADS) void fm_dense_kernel(FmDenseArgs a) {
+  __shared__ float sh[FM_DENSE_THREADS];
+  fm_dense_body(a, blockIdx.x, sh);
+}
+
 __global__ void adam_schedule_kernel(float* __restrict__ sched, float lr, float b1, float b2) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const float b1p = sched[1] * b1;
-  const float b2p = sched[2] * b2;
-  sched[1] = b1p;
-  sched[2] = b2p;
-  const float num = lr * sqrtf(1.0f - b2p);
-  sched[0] = num / (1.0f - b1p);
+  adam_schedule_body(sched, lr, b1, b2);
 }
 
+// sorted_rows == NULL: the forward alone (256-thread workgroups).  Otherwise the fused
+// forward + per-table sort (+ optimizer schedule when sched != NULL) launch.
 template <typename IDX>
-int launch_fm(const mi_fm_table& tab, const int64_t* toffs, int T, const void* ids, int B, const float* dense,
-              int n_dense, const float* wd, const float* bias, const float* labels, float gscale, float* logit,
-              float* S, float* loss_rows, float* g, int32_t* err, hipStream_t s) {
-#define FM_CASE(D)                                                                                               \
-  case D: {                                                                                                      \
-    constexpr int G_ = (D / 4) > 16 ? (D / 4) : 16;                                                              \
-    hipLaunchKernelGGL((fm_fwd_kernel<IDX, D>), dim3((unsigned) mi_cdiv(B, 256 / G_)), dim3(256), 0, s, tab, toffs, \
-                       T, ids, B, dense, n_dense, wd, bias, labels, gscale, logit, S, loss_rows, g, err);         \
-    break;                                                                                                       \
+int launch_fm(const FmFwdArgs& a, uint32_t sentinel, uint32_t* sorted_rows, uint32_t* perm, float* sched, float lr,
+              float b1, float b2, hipStream_t s) {
+#define FM_CASE(D)                                                                                                  \
+  case D: {                                                                                                         \
+    constexpr int G_ = (D / 4) > 16 ? (D / 4) : 16;                                                                 \
+    if (!sorted_rows)                                                                                               \
+      hipLaunchKernelGGL((fm_fwd_kernel<IDX, D>), dim3((unsigned) mi_cdiv(a.B, 256 / G_)), dim3(256), 0, s, a);     \
+    else                                                                                                            \
+      hipLaunchKernelGGL((fm_fwd_sort_kernel<IDX, D>), dim3((unsigned) (a.T + mi_cdiv(a.B, TS_THREADS / G_))),      \
+                         dim3(TS_THREADS), 0, s, a, a.B, sentinel, sorted_rows, perm, sched, lr, b1, b2);           \
+    break;                                                                                                          \
   }
-  switch (tab.dim) {
+  switch (a.tab.dim) {
     FM_CASE(4)
     FM_CASE(8)
     FM_CASE(16)
@@ -189,12 +81,34 @@ int launch_fm(const mi_fm_table& tab, const int64_t* toffs, int T, const void* i
     FM_CASE(64)
     FM_CASE(128)
     default:
-      mi_set_error("mi_fm_fwd: dim %d not built (4, 8, 16, 32, 64, 128)", tab.dim);
+      mi_set_error("mi_fm_fwd: dim %d not built (4, 8, 16, 32, 64, 128)", a.tab.dim);
       return MI_ERR_UNSUPPORTED;
   }
 #undef FM_CASE
   MI_LAUNCH_CHECK();
   return MI_OK;
+}
+
+int check_fwd(const char* who, const mi_fm_table* tab, const int64_t* table_offsets, int T, const void* ids,
+              int idx_bits, int64_t B, const float* dense, int n_dense, const float* wd, const float* S) {
+  const int rc = mi_fm_check_table(tab, MI_OPT_SGD, who);
+  if (rc) return rc;
+  MI_REQUIRE(table_offsets && ids, "%s: null pointer", who);
+  MI_REQUIRE(T >= 1 && B >= 0 && B < ((int64_t) 1 << 31) / T, "%s: bad T/B", who);
+  MI_REQUIRE(idx_bits == 32 || idx_bits == 64, "%s: idx_bits must be 32 or 64", who);
+  MI_REQUIRE(n_dense == 0 || (dense && wd), "%s: dense features need dense and wd", who);
+  MI_REQUIRE(((uintptr_t) S & 15) == 0, "%s: S must be 16-byte aligned", who);
+  return MI_OK;
+}
+
+FmDenseArgs dense_args(const float* g, int64_t g_ld, const float* dense, int64_t dense_ld, int n_dense, int64_t B,
+                       float* grad_out, const float* loss_rows, int64_t loss_ld, float* dp, float* dm, float* dv,
+                       float lr_t, const float* lr_dev, float b1, float b2, float eps, float* loss_out) {
+  FmDenseArgs a;
+  a.g = g; a.g_ld = g_ld; a.dense = dense; a.dense_ld = dense_ld; a.n_dense = n_dense; a.B = B;
+  a.grad_out = grad_out; a.loss_rows = loss_rows; a.loss_ld = loss_ld; a.dp = dp; a.dm = dm; a.dv = dv;
+  a.lr_t = lr_t; a.lr_dev = lr_dev; a.b1 = b1; a.b2 = b2; a.eps = eps; a.loss_out = loss_out;
+  return a;
 }
 
 }  // namespace
@@ -232,19 +146,41 @@ extern "C" int mi_fm_fwd(const mi_fm_table* tab, const int64_t* table_offsets, i
                          const float* labels, float gscale, float* logit, float* S, float* loss_rows, float* g,
                          int32_t* err, void* stream) {
   if (B == 0) return MI_OK;
-  const int rc = mi_fm_check_table(tab, MI_OPT_SGD, "mi_fm_fwd");
+  const int rc = check_fwd("mi_fm_fwd", tab, table_offsets, T, ids, idx_bits, B, dense, n_dense, wd, S);
   if (rc) return rc;
-  MI_REQUIRE(table_offsets && ids, "mi_fm_fwd: null pointer");
-  MI_REQUIRE(T >= 1 && B >= 0 && B < ((int64_t) 1 << 31) / T, "mi_fm_fwd: bad T/B");
-  MI_REQUIRE(idx_bits == 32 || idx_bits == 64, "mi_fm_fwd: idx_bits must be 32 or 64");
-  MI_REQUIRE(n_dense == 0 || (dense && wd), "mi_fm_fwd: dense features need dense and wd");
-  MI_REQUIRE(((uintptr_t) S & 15) == 0, "mi_fm_fwd: S must be 16-byte aligned");
+  const FmFwdArgs a{*tab, table_offsets, T, ids, (int) B, dense, n_dense, wd, bias, labels, gscale, logit, S, loss_rows,
+                    g, err};
   hipStream_t s = (hipStream_t) stream;
-  if (idx_bits == 32)
-    return launch_fm<int32_t>(*tab, table_offsets, T, ids, (int) B, dense, n_dense, wd, bias, labels, gscale, logit, S,
-                              loss_rows, g, err, s);
-  return launch_fm<int64_t>(*tab, table_offsets, T, ids, (int) B, dense, n_dense, wd, bias, labels, gscale, logit, S,
-                            loss_rows, g, err, s);
+  if (idx_bits == 32) return launch_fm<int32_t>(a, 0u, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, s);
+  return launch_fm<int64_t>(a, 0u, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, s);
+}
+
+extern "C" int mi_fm_fwd_sort_max_batch(void) { return TS_MAX; }
+
+extern "C" int mi_fm_fwd_sort(const mi_fm_table* tab, const int64_t* table_offsets, int T, const void* ids,
+                              int idx_bits, int64_t B, const float* dense, int n_dense, const float* wd,
+                              const float* bias, const float* labels, float gscale, float* logit, float* S,
+                              float* loss_rows, float* g, int32_t* err, int64_t total_rows, uint32_t* sorted_rows,
+                              int32_t* perm, float* sched, float lr, float beta1, float beta2, void* stream) {
+  const char* who = "mi_fm_fwd_sort";
+  const int rc = check_fwd(who, tab, table_offsets, T, ids, idx_bits, B, dense, n_dense, wd, S);
+  if (rc) return rc;
+  MI_REQUIRE(sorted_rows && perm, "%s: null sort output", who);
+  if (B < 1 || B > TS_MAX) {
+    mi_set_error("%s: batch %lld outside 1..%d (one workgroup sorts a table in LDS); use mi_fm_fwd + "
+                 "mi_embag_bwd_prepare", who, (long long) B, TS_MAX);
+    return MI_ERR_UNSUPPORTED;
+  }
+  if (total_rows < 1 || total_rows >= (int64_t) 0xFFFFFFFFll) {
+    mi_set_error("%s: total_rows %lld does not fit the uint32 row key", who, (long long) total_rows);
+    return MI_ERR_UNSUPPORTED;
+  }
+  const FmFwdArgs a{*tab, table_offsets, T, ids, (int) B, dense, n_dense, wd, bias, labels, gscale, logit, S, loss_rows,
+                    g, err};
+  hipStream_t s = (hipStream_t) stream;
+  uint32_t* pv = reinterpret_cast<uint32_t*>(perm);
+  if (idx_bits == 32) return launch_fm<int32_t>(a, (uint32_t) total_rows, sorted_rows, pv, sched, lr, beta1, beta2, s);
+  return launch_fm<int64_t>(a, (uint32_t) total_rows, sorted_rows, pv, sched, lr, beta1, beta2, s);
 }
 
 extern "C" int mi_adam_schedule_step(float* sched, float lr, float beta1, float beta2, void* stream) {
@@ -257,9 +193,9 @@ extern "C" int mi_adam_schedule_step(float* sched, float lr, float beta1, float 
 extern "C" int mi_fm_bwd_dense(const float* g, const float* dense, int n_dense, int64_t B, float* out,
                                void* stream) {
   MI_REQUIRE(g && out && n_dense >= 0 && B >= 0 && (n_dense == 0 || dense), "mi_fm_bwd_dense: bad arguments");
-  hipLaunchKernelGGL(fm_dense_kernel, dim3(n_dense + 1), dim3(1024), 0, (hipStream_t) stream, g, (int64_t) 1, dense,
-                     (int64_t) n_dense, n_dense, B, out, (const float*) nullptr, (int64_t) 1, (float*) nullptr, (float*) nullptr, (float*) nullptr, 0.f,
-                     (const float*) nullptr, 0.f, 0.f, 0.f, (float*) nullptr);
+  hipLaunchKernelGGL(fm_dense_kernel, dim3(n_dense + 1), dim3(FM_DENSE_THREADS), 0, (hipStream_t) stream,
+                     dense_args(g, 1, dense, n_dense, n_dense, B, out, nullptr, 1, nullptr, nullptr, nullptr, 0.f,
+                                nullptr, 0.f, 0.f, 0.f, nullptr));
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -269,9 +205,10 @@ extern "C" int mi_fm_dense_step(const float* g, const float* dense, int n_dense,
                                 float beta2, float eps, float* loss_out, void* stream) {
   MI_REQUIRE(g && dp && dm && dv && n_dense >= 0 && B >= 1 && (n_dense == 0 || dense), "mi_fm_dense_step: bad arguments");
   MI_REQUIRE((loss_rows == nullptr) == (loss_out == nullptr), "mi_fm_dense_step: loss_rows and loss_out go together");
-  hipLaunchKernelGGL(fm_dense_kernel, dim3(n_dense + 1 + (loss_rows ? 1 : 0)), dim3(1024), 0, (hipStream_t) stream, g,
-                     (int64_t) 1, dense, (int64_t) n_dense, n_dense, B, (float*) nullptr, loss_rows, (int64_t) 1, dp, dm, dv,
-                     lr_t, lr_dev, beta1, beta2, eps, loss_out);
+  hipLaunchKernelGGL(fm_dense_kernel, dim3(n_dense + 1 + (loss_rows ? 1 : 0)), dim3(FM_DENSE_THREADS), 0,
+                     (hipStream_t) stream,
+                     dense_args(g, 1, dense, n_dense, n_dense, B, nullptr, loss_rows, 1, dp, dm, dv, lr_t, lr_dev, beta1,
+                                beta2, eps, loss_out));
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -281,9 +218,9 @@ extern "C" int mi_fm_dense_step_rows(const float* X, int ld, int dim, int n_dens
                                      float* loss_out, void* stream) {
   MI_REQUIRE(X && dp && dm && dv && loss_out && n_dense >= 0 && n >= 1 && dim >= 1 && ld >= dim + 2 + n_dense,
              "mi_fm_dense_step_rows: bad arguments");
-  hipLaunchKernelGGL(fm_dense_kernel, dim3(n_dense + 2), dim3(1024), 0, (hipStream_t) stream, X + dim, (int64_t) ld,
-                     X + dim + 2, (int64_t) ld, n_dense, n, (float*) nullptr, X + dim + 1, (int64_t) ld, dp, dm, dv, lr_t,
-                     lr_dev, beta1, beta2, eps, loss_out);
+  hipLaunchKernelGGL(fm_dense_kernel, dim3(n_dense + 2), dim3(FM_DENSE_THREADS), 0, (hipStream_t) stream,
+                     dense_args(X + dim, ld, X + dim + 2, ld, n_dense, n, nullptr, X + dim + 1, ld, dp, dm, dv, lr_t,
+                                lr_dev, beta1, beta2, eps, loss_out));
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -21,6 +21,7 @@
 // sorted entries finds the heads of the runs that start there with a ballot.  The second form
 // saves the three run-detection launches per step.
 #include "common.h"
+#include "fm_body.h"
 
 namespace {
 
@@ -524,18 +525,39 @@ __device__ __forceinline__ void block_run(const PlanDev& pl, const Src& src, con
 constexpr int LONG_CHUNK = 1024;
 constexpr int LONG_CAP = LONG_CHUNK / (WAVE_MAX + 1) + 2;  // heads of long runs are more than WAVE_MAX apart
 
-template <int VEC, class Src, class Upd>
+//
+// Workgroups before those (`extra.blocks` of them, possibly none) do unrelated work that is ready
+// at the same time - the dense side of an FM step - so that it shares the launch instead of
+// waiting for its own.
+struct NoExtra {
+  int blocks;
+  __device__ __forceinline__ void run(int, float*) const {}
+};
+struct FmDenseExtra {
+  int blocks;
+  FmDenseArgs a;
+  __device__ __forceinline__ void run(int j, float* sh) const { fm_dense_body(a, j, sh); }
+};
+static_assert(FM_DENSE_THREADS == UBLOCK, "the dense side runs in workgroups of the sparse update's size");
+
+template <int VEC, class Src, class Upd, class Extra>
 __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src, Upd upd, int lanes, int groups,
-                                                           int long_blocks) {
+                                                           int long_blocks, Extra extra) {
   const uint32_t* keys = pl.sorted_rows;
   const uint32_t sentinel = pl.sentinel;
-  if ((int) blockIdx.x < long_blocks) {
+  if ((int) blockIdx.x < extra.blocks) {
+    __shared__ float sh[UBLOCK];
+    extra.run(blockIdx.x, sh);
+    return;
+  }
+  const int bid = blockIdx.x - extra.blocks;
+  if (bid < long_blocks) {
     __shared__ float red[UBLOCK * VEC];
     __shared__ float reds[UBLOCK];
     __shared__ int sh_end, sh_n, sh_heads[LONG_CAP];
     if (threadIdx.x == 0) sh_n = 0;
     __syncthreads();
-    const int lo = blockIdx.x * LONG_CHUNK;
+    const int lo = bid * LONG_CHUNK;
     const int hi = lo + LONG_CHUNK < pl.n ? lo + LONG_CHUNK : pl.n;
     for (int i = lo + threadIdx.x; i < hi; i += UBLOCK) {
       if (i + WAVE_MAX >= pl.n) break;
@@ -562,7 +584,7 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
     return;
   }
   const int lane = threadIdx.x & 63;
-  const int base = ((blockIdx.x - long_blocks) * (UBLOCK / 64) + (threadIdx.x >> 6)) * 64;
+  const int base = ((bid - long_blocks) * (UBLOCK / 64) + (threadIdx.x >> 6)) * 64;
   if (base >= pl.n) return;  // uniform over the wave
   const int i = base + lane;
   const uint32_t key = i < pl.n ? keys[i] : sentinel;
@@ -701,10 +723,11 @@ int check_plan(const mi_bwd_plan* plan, PlanDev* pl, bool need_runs, const char*
   return MI_OK;
 }
 
-template <class Src, class Upd>
+// `extra` (see seg_sorted_kernel) is only taken by plans without run arrays; the caller checks.
+template <class Src, class Upd, class Extra = NoExtra>
 int run_segments(const mi_bwd_plan* plan, const PlanDev& pl, const Src& src, const Upd& upd, const Geometry& g,
-                 hipStream_t s) {
-  if (plan->n_entries == 0) return MI_OK;
+                 hipStream_t s, const Extra& extra = Extra{0}) {
+  if (plan->n_entries == 0 && extra.blocks == 0) return MI_OK;
   const int wave_ok = (g.lanes <= 64 && (g.lanes & (g.lanes - 1)) == 0) ? 1 : 0;  // shuffle trees need 2^k lanes
   if (pl.seg_offsets) {
     const unsigned grid = (unsigned) mi_cdiv(plan->n_entries, g.gpb);
@@ -721,13 +744,13 @@ int run_segments(const mi_bwd_plan* plan, const PlanDev& pl, const Src& src, con
       return MI_ERR_UNSUPPORTED;
     }
     const int long_blocks = (int) mi_cdiv(plan->n_entries, LONG_CHUNK);
-    const unsigned grid = (unsigned) (long_blocks + mi_cdiv(plan->n_entries, UBLOCK));
+    const unsigned grid = (unsigned) (extra.blocks + long_blocks + mi_cdiv(plan->n_entries, UBLOCK));
     if (g.vec == 4)
-      hipLaunchKernelGGL((seg_sorted_kernel<4, Src, Upd>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes, g.gpb,
-                         long_blocks);
+      hipLaunchKernelGGL((seg_sorted_kernel<4, Src, Upd, Extra>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes,
+                         g.gpb, long_blocks, extra);
     else
-      hipLaunchKernelGGL((seg_sorted_kernel<1, Src, Upd>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes, g.gpb,
-                         long_blocks);
+      hipLaunchKernelGGL((seg_sorted_kernel<1, Src, Upd, Extra>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes,
+                         g.gpb, long_blocks, extra);
     MI_LAUNCH_CHECK();
     return MI_OK;
   }
@@ -830,9 +853,11 @@ extern "C" int mi_embag_bwd_apply_adam_dense_tf(const mi_bwd_plan* plan, const f
   return MI_OK;
 }
 
+template <class Extra>
 static int fm_bwd_apply_impl(const char* who, const mi_bwd_plan* plan, const mi_fm_table* tab, const float* g,
                              int g_ld, const float* S, int S_ld, const int32_t* entry_sample, int opt, float lr,
-                             const float* lr_dev, float beta1, float beta2, float eps, void* stream) {
+                             const float* lr_dev, float beta1, float beta2, float eps, void* stream,
+                             const Extra& extra) {
   PlanDev pl;
   int rc = check_plan(plan, &pl, false, who);
   if (rc) return rc;
@@ -852,7 +877,7 @@ static int fm_bwd_apply_impl(const char* who, const mi_bwd_plan* plan, const mi_
   switch (opt) {
     case MI_OPT_SGD: {
       FmUpd<MI_OPT_SGD> upd{*tab, a};
-      return run_segments(plan, pl, src, upd, geo, s);
+      return run_segments(plan, pl, src, upd, geo, s, extra);
     }
     case MI_OPT_ADAGRAD_ROWWISE: {
       if (!(pow2(geo.lanes) && geo.lanes <= 64)) {
@@ -860,11 +885,11 @@ static int fm_bwd_apply_impl(const char* who, const mi_bwd_plan* plan, const mi_
         return MI_ERR_UNSUPPORTED;
       }
       FmUpd<MI_OPT_ADAGRAD_ROWWISE> upd{*tab, a};
-      return run_segments(plan, pl, src, upd, geo, s);
+      return run_segments(plan, pl, src, upd, geo, s, extra);
     }
     case MI_OPT_ADAM_TF: {
       FmUpd<MI_OPT_ADAM_TF> upd{*tab, a};
-      return run_segments(plan, pl, src, upd, geo, s);
+      return run_segments(plan, pl, src, upd, geo, s, extra);
     }
     default:
       mi_set_error("%s: unknown optimizer %d", who, opt);
@@ -877,7 +902,7 @@ extern "C" int mi_fm_bwd_apply(const mi_bwd_plan* plan, const mi_fm_table* tab, 
                                float beta2, float eps, void* stream) {
   MI_REQUIRE(tab, "mi_fm_bwd_apply: null table");
   return fm_bwd_apply_impl("mi_fm_bwd_apply", plan, tab, g, 1, S, tab->dim, entry_sample, opt, lr, lr_dev, beta1,
-                           beta2, eps, stream);
+                           beta2, eps, stream, NoExtra{0});
 }
 
 extern "C" int mi_fm_bwd_apply_rows(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* X, int ld,
@@ -885,5 +910,32 @@ extern "C" int mi_fm_bwd_apply_rows(const mi_bwd_plan* plan, const mi_fm_table* 
                                     float beta2, float eps, void* stream) {
   MI_REQUIRE(tab && X && entry_sample, "mi_fm_bwd_apply_rows: null pointer");
   return fm_bwd_apply_impl("mi_fm_bwd_apply_rows", plan, tab, X + tab->dim, ld, X, ld, entry_sample, opt, lr, lr_dev,
-                           beta1, beta2, eps, stream);
+                           beta1, beta2, eps, stream, NoExtra{0});
+}
+
+extern "C" int mi_fm_bwd_apply_dense(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* g, const float* S,
+                                     int opt, float lr, const float* lr_dev, float beta1, float beta2, float eps,
+                                     const float* dense, int n_dense, const float* loss_rows, float* dp, float* dm,
+                                     float* dv, float dense_lr_t, const float* dense_lr_dev, float* loss_out,
+                                     void* stream) {
+  const char* who = "mi_fm_bwd_apply_dense";
+  MI_REQUIRE(plan && tab, "%s: null pointer", who);
+  MI_REQUIRE(g && dp && dm && dv && n_dense >= 0 && (n_dense == 0 || dense), "%s: bad dense-side arguments", who);
+  MI_REQUIRE((loss_rows == nullptr) == (loss_out == nullptr), "%s: loss_rows and loss_out go together", who);
+  const int64_t B = plan->n_bags / (plan->T > 0 ? plan->T : 1);
+  MI_REQUIRE(B >= 1, "%s: empty batch", who);
+  if (plan->unique_rows) {  // plans with run arrays take the two-launch path
+    const int rc = mi_fm_bwd_apply(plan, tab, g, S, nullptr, opt, lr, lr_dev, beta1, beta2, eps, stream);
+    if (rc) return rc;
+    return mi_fm_dense_step(g, dense, n_dense, B, loss_rows, dp, dm, dv, dense_lr_t, dense_lr_dev, beta1, beta2, eps,
+                            loss_out, stream);
+  }
+  FmDenseExtra extra;
+  extra.blocks = n_dense + 1 + (loss_rows ? 1 : 0);
+  extra.a.g = g; extra.a.g_ld = 1; extra.a.dense = dense; extra.a.dense_ld = n_dense; extra.a.n_dense = n_dense;
+  extra.a.B = B; extra.a.grad_out = nullptr; extra.a.loss_rows = loss_rows; extra.a.loss_ld = 1;
+  extra.a.dp = dp; extra.a.dm = dm; extra.a.dv = dv; extra.a.lr_t = dense_lr_t; extra.a.lr_dev = dense_lr_dev;
+  extra.a.b1 = beta1; extra.a.b2 = beta2; extra.a.eps = eps; extra.a.loss_out = loss_out;
+  return fm_bwd_apply_impl(who, plan, tab, g, 1, S, tab->dim, nullptr, opt, lr, lr_dev, beta1, beta2, eps, stream,
+                           extra);
 }

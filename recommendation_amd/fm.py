@@ -5,12 +5,15 @@ is the extension the benchmark definition names.  It reuses the colour model's b
 blocks - row gather, sort-by-row sparse backward, TensorFlow-form Adam
 (recommendation/code/model_trainer.py:157) - on 26 large tables.
 
-One training step is five entry points of the C ABI and no torch arithmetic:
+One training step is five pieces of the C ABI and no torch arithmetic:
   mi_adam_schedule_step the optimizer's scalar state (alpha_t, beta powers), kept on the device
   mi_fm_fwd            gather + pairwise term in registers + BCE loss rows + dL/dlogit
   mi_embag_bwd_prepare stable sort of (row, position)
   mi_fm_bwd_apply      per distinct row: sum_i g_i*(S_i - v) and the fused optimizer
   mi_fm_dense_step     dense-feature weight / bias gradients, their Adam update, mean loss
+Up to 8192 samples per batch the first three share ONE launch (mi_fm_fwd_sort: they need only the
+step's inputs) and the last two another (mi_fm_bwd_apply_dense: both start from dL/dlogit), so a
+step is two launches, each as long as its longest member; results are bit-identical either way.
 Parameters and optimizer state live in one record per row (ops.FmRecords), so a row's update
 touches one or two 128-byte lines.  All buffers are allocated once per batch shape: a step
 allocates nothing and can be captured in a HIP graph.
@@ -55,6 +58,8 @@ class FactorizationMachine(object):
         self._buf_B = None
         self._graphs = {}
         self._side = None
+        self.fused = True                      # set False to run the step as five separate launches
+        self._fused_max = ops.fm_fwd_sort_max_batch()
 
     # -- views ------------------------------------------------------------------------------
     @property
@@ -110,6 +115,18 @@ class FactorizationMachine(object):
         the sparse one."""
         main = torch.cuda.current_stream()
         adam = self.opt == 'adam_tf'
+        B = ids.shape[0]
+        if self.fused and B <= self._fused_max:
+            # two launches: {schedule, forward, sort} and {sparse update, dense side}
+            r = ops.fm_fwd_sort(self.table, self.toffs, ids, self.plan, dense if self.n_dense else None,
+                                self.wd if self.n_dense else None, self.bias, labels, 1.0 / B, self.err,
+                                out=self._buffers(ids), sched=self.sched, lr=self.lr, beta1=self.beta1,
+                                beta2=self.beta2)
+            ops.fm_bwd_apply_dense(self.plan, self.table, r['g'], r['S'], _OPT[self.opt], self.lr, self.beta1,
+                                   self.beta2, self.eps, dense if self.n_dense else None, r['loss_rows'], self.dp,
+                                   self.dm, self.dv, self.loss, lr_dev=self.sched if adam else None,
+                                   dense_lr_dev=self.sched)
+            return
         if streams:
             streams[0].wait_stream(main)
             with torch.cuda.stream(streams[0]):

@@ -413,6 +413,43 @@ def fm_bwd_apply(plan, table, g, S, opt, lr, beta1=0.9, beta2=0.999, eps=1e-8, l
               beta2, eps, _stream())
 
 
+def fm_fwd_sort_max_batch():
+    return int(_lib.load().mi_fm_fwd_sort_max_batch())
+
+
+def fm_fwd_sort(table, toffs, ids, plan, dense=None, wd=None, bias=None, labels=None, gscale=1.0, err=None, out=None,
+                sched=None, lr=0.0, beta1=0.9, beta2=0.999):
+    """fm_fwd + the sort of ``plan`` (built without run arrays for ids of this shape) + one optimizer
+    schedule step (``sched``), one launch.  Returns what fm_fwd returns; ``plan`` is ready for the apply."""
+    _need_cuda(table.rec, toffs, ids, dense, wd, bias, labels, err, sched)
+    B, T = ids.shape
+    if plan.runs or plan.n_entries != B * T or plan.bag_len != 1 or plan.T != T:
+        raise MiError("fm_fwd_sort: the plan must be built with runs=False for ids of this shape")
+    buf = out or {}
+    f32 = dict(dtype=torch.float32, device=table.rec.device)
+    logit = buf['logit'] if buf.get('logit') is not None else torch.empty((B,), **f32)
+    S = buf['S'] if buf.get('S') is not None else torch.empty((B, table.dim), **f32)
+    loss_rows = g = None
+    if labels is not None:
+        loss_rows = buf['loss_rows'] if buf.get('loss_rows') is not None else torch.empty((B,), **f32)
+        g = buf['g'] if buf.get('g') is not None else torch.empty((B,), **f32)
+    n_dense = dense.shape[1] if dense is not None else 0
+    ids = ids.contiguous()
+    _lib.call('mi_fm_fwd_sort', table.ref(), _p(toffs), T, _p(ids), _idx_bits(ids), B, _p(dense), n_dense, _p(wd),
+              _p(bias), _p(labels), gscale, _p(logit), _p(S), _p(loss_rows), _p(g), _p(err), plan.total_rows,
+              _p(plan.sorted_rows), _p(plan.perm), _p(sched), lr, beta1, beta2, _stream())
+    return dict(logit=logit, S=S, loss_rows=loss_rows, g=g)
+
+
+def fm_bwd_apply_dense(plan, table, g, S, opt, lr, beta1, beta2, eps, dense, loss_rows, dp, dm, dv, loss_out,
+                       lr_dev=None, dense_lr_t=0.0, dense_lr_dev=None):
+    """fm_bwd_apply (step size lr / lr_dev) + fm_dense_step (dense_lr_t / dense_lr_dev), one launch."""
+    n_dense = dense.shape[1] if dense is not None else 0
+    _lib.call('mi_fm_bwd_apply_dense', plan.ref(), table.ref(), _p(g), _p(S), opt, lr, _p(lr_dev), beta1, beta2, eps,
+              _p(dense), n_dense, _p(loss_rows), _p(dp), _p(dm), _p(dv), dense_lr_t, _p(dense_lr_dev), _p(loss_out),
+              _stream())
+
+
 def fm_bwd_dense(g, dense, out=None):
     n_dense = dense.shape[1] if dense is not None else 0
     if out is None:

@@ -486,3 +486,34 @@ def test_fm_graph_replay_equals_eager_bitwise(dev, opt):
     # and the device-resident schedule is TensorFlow's fp32 schedule
     alpha, _, _ = oe.tf_adam_scalars(1e-2, 0.9, 0.999, 4)
     assert float(a.sched[0].item()) == np.float32(alpha)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad_rowwise", "adam_tf"])
+@pytest.mark.parametrize("B", [700, 4096, 8192])
+def test_fm_two_launch_step_equals_five_launch_step_bitwise(dev, opt, B):
+    """{schedule, forward, sort} in one launch and {sparse update, dense side} in another must leave
+    exactly the bits of the five separate launches, eager and under graph replay."""
+    from recommendation_amd.fm import FactorizationMachine
+    rows = [1460, 583, 30000, 305, 24, 3, 10, 4, 18, 15, 105, 27, 2173]
+    ref = ofm.State(rows, 16, 13, seed=7, opt=opt)
+    models = [FactorizationMachine(rows, 16, 13, device=dev, opt=opt, lr=1e-2) for _ in range(3)]
+    for m in models:
+        m.load_state(ref)
+    models[0].fused = False
+    bufs = None
+    for step in range(3):
+        arrs = ofm.synthetic_batch(B, rows, 13, seed=50 + step, dist='zipf')
+        if bufs is None:
+            bufs = tuple(torch.from_numpy(x).to(dev) for x in arrs)
+        else:
+            for dst, src in zip(bufs, arrs):
+                dst.copy_(torch.from_numpy(src))
+        l0 = models[0].train_step(*bufs).clone()
+        l1 = models[1].train_step(*bufs).clone()
+        l2 = models[2].train_step(*bufs, graph=True).clone()
+        assert torch.equal(l0, l1) and torch.equal(l0, l2)
+        assert torch.equal(models[0].plan.sorted_rows, models[1].plan.sorted_rows)
+        assert torch.equal(models[0].plan.perm, models[1].plan.perm)
+    for m in models[1:]:
+        assert torch.equal(models[0].table.rec, m.table.rec)
+        assert torch.equal(models[0].dp, m.dp) and torch.equal(models[0].sched, m.sched)
