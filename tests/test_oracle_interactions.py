@@ -1,0 +1,61 @@
+"""The numpy restatements of DCN-v2 and the DIN unit are themselves pinned: their analytic
+gradients must agree with central finite differences of their own forward, and bf16_round must be
+round-to-nearest-even."""
+import numpy as np
+import torch
+
+from oracle import dcn as odcn
+from oracle import din as odin
+from oracle import fm as ofm
+
+
+def _fd(loss_fn, arr, idx, h=1e-3):
+    old = arr[idx]
+    arr[idx] = old + h
+    lp = loss_fn()
+    arr[idx] = old - h
+    lm = loss_fn()
+    arr[idx] = old
+    return (lp - lm) / (2 * h)
+
+
+def test_dcn_gradients_match_finite_differences():
+    rows = [50, 7, 120, 3]
+    st = odcn.State(rows, 4, 3, n_cross=2, mlp=(16, 8), seed=1)
+    ids, dense, labels = ofm.synthetic_batch(6, rows, 3, seed=2)
+    _, gr, uniq, dV, _ = odcn.grads(st, ids, dense, labels)
+
+    def loss():
+        per, _ = ofm.bce_with_logits(odcn.forward(st, ids, dense), labels.astype(np.float64))
+        return per.mean()
+
+    for name, idx in [('cross0/W', (1, 2)), ('cross1/W', (0, 5)), ('cross1/b', (3,)), ('mlp0/W', (2, 5)),
+                      ('mlp1/b', (1,)), ('out/w', (2,)), ('out/b', (0,))]:
+        assert abs(_fd(loss, st.dense_params()[name], idx) - gr[name][idx]) <= 1e-5 + 1e-3 * abs(gr[name][idx]), name
+    for i in (0, len(uniq) // 2, len(uniq) - 1):
+        assert abs(_fd(loss, st.V, (uniq[i], 1)) - dV[i, 1]) <= 1e-5 + 1e-3 * abs(dV[i, 1])
+
+
+def test_din_gradients_match_finite_differences():
+    st = odin.State(50, dim=4, h1=6, h2=5, seed=1)
+    hist, qid, lens, labels = odin.synthetic_batch(5, 7, 50, seed=2)
+    hist[0, 0] = -1
+    _, gr, uniq, dE, _ = odin.grads(st, hist, qid, lens, labels)
+
+    def loss():
+        per, _ = ofm.bce_with_logits(odin.forward(st, hist, qid, lens), labels.astype(np.float64))
+        return per.mean()
+
+    for name, idx in [('lau/W1', (1, 9)), ('lau/b1', (3,)), ('lau/W2', (2, 5)), ('lau/b2', (0,)), ('lau/w3', (1,)),
+                      ('lau/b3', (0,)), ('out/W', (6,)), ('out/b', (0,))]:
+        assert abs(_fd(loss, st.dense_params()[name], idx) - gr[name][idx]) <= 1e-5 + 1e-3 * abs(gr[name][idx]), name
+    for i in (0, len(uniq) // 2, len(uniq) - 1):
+        assert abs(_fd(loss, st.E, (uniq[i], 1)) - dE[i, 1]) <= 1e-5 + 1e-3 * abs(dE[i, 1])
+
+
+def test_bf16_round_is_round_to_nearest_even():
+    a = (np.random.default_rng(0).standard_normal(100000) * 3).astype(np.float32)
+    a[:6] = [0, 1.00390625, 1.01171875, -2.5, 3e-40, 65504.0]
+    want = torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+    assert np.array_equal(odcn.bf16_round(a), want)
+    assert odcn.bf16_round(a.astype(np.float64)).dtype == np.float64
