@@ -474,6 +474,21 @@ int mi_din_lau_scatter(const void* A, const void* dA, const float* a, const floa
 int mi_bce_logits(const float* logits, const float* labels, int64_t B, float gscale,
                   float* loss_rows, float* g, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Host-side tokenizer of the record wire format (no GPU work; all pointers are HOST memory).
+ * A record is one line "user country l1 click1 l2 click2 [label]" with space-separated fields,
+ * l1 / l2 comma-separated id lists of bag_len entries: r_model.py:143-177 (Sample.read_csv /
+ * read_label_data: tf.decode_csv(field_delim=' ') with record_defaults [0, 0, '0,0,0,0,0,0', 0,
+ * '0,0,0,0,0,0', 0(, 0)], tf.string_split(sep=',') + to_number on the two list fields).
+ * Parses at most max_rows records from text[0..len):
+ *   scalars[row][n_fields-2]  the int32 scalar fields in record order
+ *   bags[row][2][bag_len]     the two lists
+ * n_rows = records parsed, consumed = bytes of text they (and skipped blank lines) took.  Any
+ * malformed record (field count, non-int32 value, list length != bag_len) is an error, as it is
+ * for decode_csv; mi_last_error() names the line. */
+int mi_parse_records(const char* text, int64_t len, int n_fields, int bag_len, int64_t max_rows,
+                     int32_t* scalars, int32_t* bags, int64_t* n_rows, int64_t* consumed);
+
 #ifdef __cplusplus
 }
 #endif

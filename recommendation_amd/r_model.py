@@ -364,11 +364,44 @@ def parse_record(line, n_fields):
     return out
 
 
-class Dataset(object):
-    """The slice of tf.data the reference uses: lines -> map(parse_csv) -> repeat -> batch."""
+def parse_records(text, n_fields, bag_len=6, max_rows=None):
+    """Many text records at once through the library's host-side tokenizer (mi_parse_records): the
+    same grammar as parse_record, every list field exactly ``bag_len`` long.  ``text``: bytes or str.
+    Returns (columns, consumed): the n_fields int32 numpy columns in record order (list fields as
+    [n, bag_len]) and the number of bytes taken."""
+    import ctypes
+    from . import _lib
+    if isinstance(text, str):
+        text = text.encode()
+    if max_rows is None:
+        max_rows = text.count(b'\n') + 1
+    scalars = np.empty((max_rows, n_fields - 2), dtype=np.int32)
+    bags = np.empty((max_rows, 2, bag_len), dtype=np.int32)
+    n, used = ctypes.c_int64(0), ctypes.c_int64(0)
+    try:
+        _lib.call('mi_parse_records', text, len(text), n_fields, bag_len, max_rows, scalars.ctypes.data,
+                  bags.ctypes.data, ctypes.byref(n), ctypes.byref(used))
+    except _lib.MiError as e:
+        raise InvalidArgumentError(str(e))
+    n = n.value
+    cols, si = [], 0
+    for k in range(n_fields):
+        if k in (2, 4):
+            cols.append(np.ascontiguousarray(bags[:n, 0 if k == 2 else 1]))
+        else:
+            cols.append(np.ascontiguousarray(scalars[:n, si]))
+            si += 1
+    return tuple(cols), used.value
 
-    def __init__(self, line_source, n_fields, batch_size, repeat):
+
+class Dataset(object):
+    """The slice of tf.data the reference uses: lines -> map(parse_csv) -> repeat -> batch.
+    A batch of lines is tokenised by one call of the library's host-side tokenizer; set
+    ``fast=False`` to parse record by record in Python (same results, used as the cross-check)."""
+
+    def __init__(self, line_source, n_fields, batch_size, repeat, fast=True):
         self._source, self._n_fields, self._batch, self._repeat = line_source, n_fields, batch_size, repeat
+        self._fast = fast
 
     def _lines(self):
         epoch = 0
@@ -384,6 +417,10 @@ class Dataset(object):
             epoch += 1
 
     def __iter__(self):
+        if self._fast:
+            for cols in self._iter_fast():
+                yield cols
+            return
         rows = []
         for ln in self._lines():
             rows.append(parse_record(ln, self._n_fields))
@@ -392,6 +429,23 @@ class Dataset(object):
                 rows = []
         if rows:                       # tf.data batch() keeps the final partial batch
             yield self._stack(rows)
+
+    def _iter_fast(self):
+        lines, bag_len = [], None
+        def flush():
+            text = '\n'.join(l.rstrip('\r\n') for l in lines)
+            cols, _ = parse_records(text, self._n_fields, bag_len, len(lines))
+            return tuple(torch.from_numpy(c) for c in cols)
+        for ln in self._lines():
+            if bag_len is None:        # the batch's list width (tf.sparse.to_dense needs one width per batch)
+                f = ln.rstrip('\r\n').split(' ')
+                bag_len = max(1, len([t for t in f[2].split(',') if t != ''])) if len(f) > 2 and f[2] != '' else 6
+            lines.append(ln)
+            if len(lines) == self._batch:
+                yield flush()
+                lines = []
+        if lines:
+            yield flush()
 
     def _stack(self, rows):
         cols = []
