@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument('--cpu-steps', type=int, default=20)
     ap.add_argument('--stage-reps', type=int, default=50)
     ap.add_argument('--no-graph', action='store_true', help='launch the step eagerly instead of replaying a HIP graph')
-    ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din'],
+    ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer'],
                     help='fm (default, the headline configuration); dcn / din: the bf16 matrix-core configurations, 1 GPU')
     return ap.parse_args()
 
@@ -305,8 +305,29 @@ def bench_din(args):
     return res
 
 
+def bench_infer(args):
+    """ModelInference.inference on record strings (tokenizer + colour-model forward + top-6 + string
+    formatting): the serving-side consumer of the forward path, batch 4096 unless --batch is given."""
+    from oracle import colour_model as cm
+    from recommendation_amd.inference import ModelInference
+    B = args.batch if args.batch != 8192 else 4096
+    batch = cm.synthetic_batch(B, seed=1, with_label=False)
+    records = [cm.format_record(batch, i, with_label=False) for i in range(B)]
+    mi = ModelInference(device=torch.device('cuda', 0))
+    dt = _timed_steps(lambda: mi.inference(records), args)
+    res = _line(args, 'colour_model_inference_b%d' % B, B, dt, 'f32',
+                dict(model='RecommendationModel(128, 6, 100, 20)', includes='record tokenizer, forward, top-6, result strings'))
+    res['metric'] = 'inference_records_per_sec'
+    res['unit'] = 'records/s'
+    return res
+
+
 def main():
     args = parse_args()
+    if args.workload == 'infer':
+        torch.cuda.set_device(0)
+        print(json.dumps(bench_infer(args)))
+        return
     if args.workload != 'fm':
         if args.gpus != 1 or int(os.environ.get('WORLD_SIZE', '1')) != 1:
             raise SystemExit("--workload %s is a single-GPU configuration" % args.workload)
