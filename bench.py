@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument('--cpu-steps', type=int, default=20)
     ap.add_argument('--stage-reps', type=int, default=50)
     ap.add_argument('--no-graph', action='store_true', help='launch the step eagerly instead of replaying a HIP graph')
+    ap.add_argument('--force-sharded', action='store_true',
+                    help='use the row-wise sharded model and its collectives even with one rank (rehearsal of the N > 1 path)')
     ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer'],
                     help='fm (default, the headline configuration); dcn / din: the bf16 matrix-core configurations, 1 GPU')
     return ap.parse_args()
@@ -344,12 +346,18 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29577')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         torch.distributed.init_process_group('nccl', device_id=dev)
 
     rows = CRITEO_KAGGLE
     B = args.batch
-    if world == 1:
+    if not sharded:
         from recommendation_amd.fm import FactorizationMachine
         model = FactorizationMachine(rows, args.dim, 13, device=dev, opt=args.opt, lr=1e-3, seed=0)
     else:
@@ -358,11 +366,11 @@ def main():
     batches = gen_batches(8, B, rows, 13, args.dist, args.idx_bits, dev, seed=1000 + rank)
 
     def barrier():
-        if world > 1:
+        if sharded:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = (not sharded) and not args.no_graph
     kw = {'graph': True} if use_graph else {}
     for i in range(max(args.warmup, len(batches) if use_graph else 0)):   # every batch's graph captured before timing
         model.train_step(*batches[i % len(batches)], **kw)
@@ -372,7 +380,7 @@ def main():
         model.train_step(*batches[i % len(batches)], **kw)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -390,9 +398,9 @@ def main():
                        'tables': len(rows), 'total_rows': int(sum(rows)), 'dim': args.dim, 'n_dense': 13,
                        'id_bits': args.idx_bits, 'ids': args.dist, 'optimizer': args.opt,
                        'launch': 'hip graph replay' if use_graph else 'eager',
-                       'parallelism': 'single' if world == 1 else 'rowwise-sharded tables x%d + dp dense' % world},
+                       'parallelism': 'single' if not sharded else 'rowwise-sharded tables x%d + replicated dense' % world},
         }
-    if world == 1:
+    if not sharded:
         stages, U = stage_report(model, batches[0], args.stage_reps, args.idx_bits)
         hbm = [s for s in stages if s['name'].startswith(('fm_fwd', 'fm_bwd_apply'))]
         upd = [s for s in stages if s['name'].startswith('launch 2')]
@@ -418,7 +426,7 @@ def main():
             result['cpu_baseline'] = cpu_baseline(args, rows, model, batches)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if sharded:
         torch.distributed.destroy_process_group()
 
 

@@ -13,10 +13,10 @@
 // transposing read (ds_read_b64_tr_b16), so no transposed copy of any activation or weight is
 // ever written to HBM.
 //
-// Each wave owns a 64x64 block of the result (4x4 fragments of mfma_f32_16x16x32_bf16); a
-// workgroup is WM x WN waves (256x128x64 tiles with 8 waves for the big contractions, 128x128x64
-// with 4 for narrow ones).  Tiles are staged global -> LDS by DMA up to STAGES-1 tiles ahead,
-// retired with counted vmcnt waits and ONE raw barrier per K tile.
+// A wave owns FM x FN fragments of mfma_f32_16x16x32_bf16 (128x64 or 64x64 results); a workgroup
+// is WM x WN waves (256x256x64 tiles with 8 waves, or 128x128x64 with 4).  Tiles are staged
+// global -> LDS by DMA one tile ahead, retired with a counted vmcnt wait and ONE raw barrier per
+// K tile; inside a tile the fragment reads run three MFMA rows ahead of the MFMAs that use them.
 #include "common.h"
 
 namespace {
@@ -48,29 +48,45 @@ __device__ __forceinline__ int tr_img(int kr, int ch) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// The per-lane source pointers of a wave's pieces at k = 0 are computed once (src_init); staging a
+// K tile then costs one 64-bit add, one M0 write and one DMA instruction per piece.
 template <bool TR, int NSUB, int NWAVES>
-__device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ P, int64_t ld, int64_t row0, int64_t R,
-                                           int64_t k0, char* lds, int wave, int lane) {
-  constexpr int PER_WAVE = NSUB * 16 / NWAVES;
+struct Stager {
+  static constexpr int PER_WAVE = NSUB * 16 / NWAVES;
+  const unsigned short* src[PER_WAVE];
+  int64_t kstride;  // elements per unit of k
+  __device__ __forceinline__ void init(const unsigned short* __restrict__ P, int64_t ld, int64_t row0, int64_t R,
+                                       int wave, int lane) {
+    kstride = TR ? ld : 1;
 #pragma unroll
-  for (int i = 0; i < PER_WAVE; ++i) {
-    const int gp = __builtin_amdgcn_readfirstlane(wave + NWAVES * i);  // piece of the whole tile
-    const int sub = gp >> 4, piece = gp & 15;
-    const unsigned short* src;
-    if constexpr (!TR) {
-      const int r = piece * 8 + (lane >> 3), ch = (lane & 7) ^ (r & 7);
-      int64_t rr = row0 + sub * 128 + r;
-      rr = rr < R ? rr : R - 1;  // out-of-range rows read a valid row; their results are never stored
-      src = P + rr * ld + k0 + ch * 8;
-    } else {
-      const int kr = piece * 4 + (lane >> 4), ch = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
-      int64_t m = row0 + sub * 128 + ch * 8;
-      m = m <= R - 8 ? m : R - 8;
-      src = P + (k0 + kr) * ld + m;
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int gp = wave + NWAVES * i;  // piece of the whole tile
+      const int sub = gp >> 4, piece = gp & 15;
+      if constexpr (!TR) {
+        const int r = piece * 8 + (lane >> 3), ch = (lane & 7) ^ (r & 7);
+        int64_t rr = row0 + sub * 128 + r;
+        rr = rr < R ? rr : R - 1;  // out-of-range rows read a valid row; their results are never stored
+        src[i] = P + rr * ld + ch * 8;
+      } else {
+        const int kr = piece * 4 + (lane >> 4), ch = (lane & 15) ^ (((kr & 3) << 2) | ((kr >> 2) & 3));
+        int64_t m = row0 + sub * 128 + ch * 8;
+        m = m <= R - 8 ? m : R - 8;
+        src[i] = P + kr * ld + m;
+      }
     }
-    __builtin_amdgcn_global_load_lds((gptr_t) src, (lptr_t) (lds + gp * 1024), 16, 0, 0);
   }
-}
+  __device__ __forceinline__ void stage_one(int i, int64_t k0, char* lds, int wave) const {
+    const int gp = __builtin_amdgcn_readfirstlane(wave + NWAVES * i);
+    __builtin_amdgcn_global_load_lds((gptr_t) (src[i] + k0 * kstride), (lptr_t) (lds + gp * 1024), 16, 0, 0);
+  }
+  __device__ __forceinline__ void stage(int64_t k0, char* lds, int wave) const {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int gp = __builtin_amdgcn_readfirstlane(wave + NWAVES * i);
+      __builtin_amdgcn_global_load_lds((gptr_t) (src[i] + k0 * kstride), (lptr_t) (lds + gp * 1024), 16, 0, 0);
+    }
+  }
+};
 
 // fragment f (16 rows of the tile), k-step kk (32 of the tile's 64 k): lane l gets row l&15,
 // k = 8*(l>>4) + 0..7
@@ -177,13 +193,15 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool A_TR, bool B_TR, int WM, int WN, int STAGES>
+template <bool A_TR, bool B_TR, int WM, int WN, int FM, int FN, int STAGES>
 __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_bf16_kernel(GemmArgs a) {
-  constexpr int NWAVES = WM * WN, BM = 64 * WM, BN = 64 * WN;
+  // a wave owns FM x FN fragments of 16x16; the workgroup is WM x WN waves
+  constexpr int NWAVES = WM * WN, BM = 16 * FM * WM, BN = 16 * FN * WN;
   constexpr int A_SUB = BM / 128, B_SUB = BN / 128;
   constexpr int A_BYTES = A_SUB * SUB_BYTES, B_BYTES = B_SUB * SUB_BYTES;
   constexpr int PER_TILE = (A_SUB + B_SUB) * 16 / NWAVES;  // DMA instructions per wave and K tile
   constexpr int D = STAGES - 1;                             // tiles in flight ahead of the one being multiplied
+  constexpr bool INTERLEAVE = NWAVES == 8;                  // spread the DMA over the MFMA rows (one workgroup per CU)
   static_assert(BM % 128 == 0 && BN % 128 == 0 && (A_SUB * 16) % NWAVES == 0 && (B_SUB * 16) % NWAVES == 0, "tile");
   static_assert(D >= 1 && D <= 3, "stages");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -201,17 +219,21 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_bf16_kernel(GemmArgs a) {
   const int ktiles = (int) ((kend - kbeg) / BK);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w / WN, wc = w % WN;
 
-  f4v acc[4][4];
+  f4v acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
 
-#define STAGE(kt_, buf_)                                                                                             \
-  do {                                                                                                               \
-    const int64_t k0_ = kbeg + (int64_t) (kt_) * BK;                                                                 \
-    stage_tile<A_TR, A_SUB, NWAVES>(a.A, a.lda, m0, a.M, k0_, As + (buf_) * A_BYTES, w, lane);                       \
-    stage_tile<B_TR, B_SUB, NWAVES>(a.B, a.ldb, n0, a.N, k0_, Bs + (buf_) * B_BYTES, w, lane);                       \
+  Stager<A_TR, A_SUB, NWAVES> sta;
+  Stager<B_TR, B_SUB, NWAVES> stb;
+  sta.init(a.A, a.lda, m0, a.M, w, lane);
+  stb.init(a.B, a.ldb, n0, a.N, w, lane);
+#define STAGE(kt_, buf_)                                             \
+  do {                                                               \
+    const int64_t k0_ = kbeg + (int64_t) (kt_) * BK;                 \
+    sta.stage(k0_, As + (buf_) * A_BYTES, w);                        \
+    stb.stage(k0_, Bs + (buf_) * B_BYTES, w);                        \
   } while (0)
 
 #pragma unroll
@@ -228,56 +250,78 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_bf16_kernel(GemmArgs a) {
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + D < ktiles) {
-      int nxt = cur + D;
-      nxt = nxt >= STAGES ? nxt - STAGES : nxt;
-      STAGE(kt + D, nxt);
-    }
+    const bool more = kt + D < ktiles;
+    int nxt = cur + D;
+    nxt = nxt >= STAGES ? nxt - STAGES : nxt;
+    const int64_t knext = kbeg + (int64_t) (kt + D) * BK;
+    constexpr int A_PER = A_SUB * 16 / NWAVES, B_PER = B_SUB * 16 / NWAVES;
+    constexpr int ROWS = 2 * FM;                                   // MFMA rows of a K tile: k-step 0, then k-step 1
+    constexpr int PPR = (A_PER + B_PER + ROWS - 1) / ROWS;         // DMA pieces per MFMA row
+    constexpr int RING = 3;                                        // A fragments in flight ahead of the MFMAs
+    static_assert(FM >= FN && FM >= RING, "wave tile");
     const char* Ac = As + cur * A_BYTES;
     const char* Bc = Bs + cur * B_BYTES;
+    // Software pipeline over the 2*FM MFMA rows of the tile.  Only the B fragments of a k-step
+    // (FN of them) stay resident; A fragments stream through a ring of three, each read three rows
+    // before the MFMAs that use it, and the B fragments of k-step 1 arrive during the last rows of
+    // k-step 0.  With interleaved staging one DMA piece of the next tile goes out per row, in the
+    // MFMAs' shadow, instead of a burst after the barrier when every wave would issue it at once.
+    s8v fb[2][FN], fa[RING];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      s8v fa[4], fb[4];
+    for (int j = 0; j < FN; ++j) fb[0][j] = read_frag<B_TR>(Bc, wc * FN + j, 0, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_TR>(Ac, wr * 4 + i, kk, lane);
+    for (int q = 0; q < RING; ++q) fa[q] = read_frag<A_TR>(Ac, wr * FM + q, 0, lane);
+    if (!INTERLEAVE && more) STAGE(kt + D, nxt);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_TR>(Bc, wc * 4 + j, kk, lane);
+    for (int r = 0; r < ROWS; ++r) {
+      constexpr int dummy = 0;
+      (void) dummy;
+      const int kk = r / FM, i = r % FM;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < FN; ++j)
+        // first operand indexes the result's rows (kept in registers): n; second its columns (lanes): m
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, fb[kk][j]),
+                                                            __builtin_bit_cast(bf8v, fa[r % RING]), acc[i][j], 0, 0, 0);
+      if (INTERLEAVE && more) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          // first operand indexes the result's rows (kept in registers): n; second its columns (lanes): m
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, fb[j]),
-                                                              __builtin_bit_cast(bf8v, fa[i]), acc[i][j], 0, 0, 0);
+        for (int q = 0; q < PPR; ++q) {
+          const int pc = r * PPR + q;
+          if (pc < A_PER) sta.stage_one(pc, knext, As + nxt * A_BYTES, w);
+          else if (pc < A_PER + B_PER) stb.stage_one(pc - A_PER, knext, Bs + nxt * B_BYTES, w);
+        }
+      }
+      if (r + RING < ROWS) fa[r % RING] = read_frag<A_TR>(Ac, wr * FM + (r + RING) % FM, (r + RING) / FM, lane);
+      if (kk == 0 && i >= FM - FN) fb[1][i - (FM - FN)] = read_frag<B_TR>(Bc, wc * FN + i - (FM - FN), 1, lane);
+      __builtin_amdgcn_sched_barrier(0);
     }
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
 #undef STAGE
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + wr * 64 + i * 16 + (lane & 15);
+  for (int i = 0; i < FM; ++i) {
+    const int64_t m = m0 + (wr * FM + i) * 16 + (lane & 15);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+    for (int j = 0; j < FN; ++j) {
+      const int64_t n = n0 + (wc * FN + j) * 16 + (lane >> 4) * 4;
       if (m < a.M && n < a.N) epilogue(a.e, a.M, a.N, z, m, n, make_float4(acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w));
     }
   }
 }
 
-template <bool A_TR, bool B_TR, int WM, int WN, int STAGES>
+template <bool A_TR, bool B_TR, int WM, int WN, int FM, int FN, int STAGES>
 int launch_gemm(GemmArgs& g, int splits, hipStream_t s) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int BM = 16 * FM * WM, BN = 16 * FN * WN;
   constexpr size_t lds = (size_t) STAGES * (BM + BN) * BK * 2;
   static bool configured = false;  // per instantiation; racing first calls set the same value
   if (lds > 64 * 1024 && !configured) {
-    MI_HIP(hipFuncSetAttribute((const void*) gemm_bf16_kernel<A_TR, B_TR, WM, WN, STAGES>,
+    MI_HIP(hipFuncSetAttribute((const void*) gemm_bf16_kernel<A_TR, B_TR, WM, WN, FM, FN, STAGES>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     configured = true;
   }
   g.tiles_n = (int) mi_cdiv(g.N, BN);
   const int64_t tiles = mi_cdiv(g.M, BM) * g.tiles_n;
   MI_REQUIRE(tiles < ((int64_t) 1 << 31), "mi_gemm_bf16: too many tiles");
-  hipLaunchKernelGGL((gemm_bf16_kernel<A_TR, B_TR, WM, WN, STAGES>), dim3((unsigned) tiles, (unsigned) splits),
+  hipLaunchKernelGGL((gemm_bf16_kernel<A_TR, B_TR, WM, WN, FM, FN, STAGES>), dim3((unsigned) tiles, (unsigned) splits),
                      dim3(WM * WN * 64), lds, s, g);
   MI_LAUNCH_CHECK();
   return MI_OK;
@@ -285,10 +329,16 @@ int launch_gemm(GemmArgs& g, int splits, hipStream_t s) {
 
 template <bool A_TR, bool B_TR>
 int dispatch_gemm(GemmArgs& g, int splits, hipStream_t s) {
-  // 128x128 tiles, two stages, two workgroups per CU.  A 256x128 tile with three stages (8 waves,
-  // 144 KiB of LDS, one workgroup per CU) was measured 4-13 % SLOWER on the 65536-row shapes here
-  // (609 vs 634 TFLOP/s forward, 568 vs 654 for the weight gradient), so it is not instantiated.
-  return launch_gemm<A_TR, B_TR, 2, 2, 2>(g, splits, s);
+  // Two workgroup shapes (measured on the 65536-row shapes of a DCN-v2 step, TFLOP/s):
+  //   256x256, 8 waves x (128x64), 128 KiB LDS, 1 workgroup/CU:  forward 827-862, dX 435-536, dW 241-429
+  //   128x128, 4 waves x (64x64),   64 KiB LDS, 2 workgroups/CU: forward 719-757, dX 388-560, dW 652-695
+  // The big tile halves the LDS and L2 bytes per flop and wins whenever the operands are read the
+  // way they lie (ds_read_b128); with both operands reduction-major (weight gradients) its
+  // transposing reads and 241 VGPRs lose, and narrow outputs do not fill its 256 columns.
+  const int64_t big = mi_cdiv(g.M, 256) * mi_cdiv(g.N, 256) * splits;
+  const bool fills = mi_cdiv(g.N, 256) * 256 * 100 <= g.N * 115;  // at most 15 % of the columns are padding
+  if (!A_TR && big >= 128 && fills && (!B_TR || g.N >= 512)) return launch_gemm<A_TR, B_TR, 2, 4, 8, 4, 2>(g, splits, s);
+  return launch_gemm<A_TR, B_TR, 2, 2, 4, 4, 2>(g, splits, s);
 }
 
 bool al16p(const void* p) { return ((uintptr_t) p & 15) == 0; }
