@@ -370,10 +370,8 @@ int mi_fm_dense_step_rows(const float* X, int ld, int dim, int n_dense, int64_t 
 #define MI_EPI_BIAS_ACT 1  /* out (bf16) = act(C + bias[n]); flags & MI_EPI_RELU */
 #define MI_EPI_CROSS_FWD 2 /* u = C + bias -> out1 (bf16, optional); out (bf16) = in0 * u + in1 */
 #define MI_EPI_MASK 3      /* out (bf16) = C where in0 > 0 else 0 (in0 NULL: plain store) */
-#define MI_EPI_CROSS_BWD 4 /* v = C + in1 (optional) -> out (bf16, optional); with out1: out1 = v*in0,
-                              facc += v*in2; without: facc += v.  MI_EPI_INIT: facc starts at 0 */
+#define MI_EPI_CROSS_BWD 4 /* v = C + in1 (bf16, optional) -> out (bf16); with out1: out1 (bf16) = v * in0 */
 #define MI_EPI_RELU 1
-#define MI_EPI_INIT 2
 
 typedef struct mi_gemm_epilogue {
   int mode, flags;
@@ -384,12 +382,8 @@ typedef struct mi_gemm_epilogue {
   int64_t ld_in0;
   const void* in1;
   int64_t ld_in1;
-  const void* in2;
-  int64_t ld_in2;
   void* out1;
   int64_t ld_out1;
-  float* facc;
-  int64_t ld_facc;
 } mi_gemm_epilogue;
 
 /* C[m][n] = sum_k A(m,k)*B(n,k), followed by the epilogue.  An operand is stored either
@@ -435,6 +429,13 @@ int mi_head_bwd(const float* g, const float* w, const void* h, int64_t ld_h, int
 
 /* out (bf16) = in (fp32). */
 int mi_cast_bf16(const float* in, int64_t n, void* out, void* stream);
+
+/* Gradient of the cross network's input x0 (x_{l+1} = x0*u_l + x_l, L layers, L <= 8):
+ *   out[m][n] (fp32) = dx[0][m][n] + sum_{l < L} dx[l+1][m][n] * u[l][m][n]
+ * dx[0..L] and u[0..L-1] are host arrays of device pointers to bf16 [M][ld] tensors (what the
+ * MI_EPI_CROSS_BWD / MI_EPI_CROSS_FWD epilogues stored); n < N, N % 4 == 0. */
+int mi_cross_input_grad(const void* const* dx, const void* const* u, int L, int64_t M, int N,
+                        int64_t ld, float* out, int64_t ld_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DIN local activation unit (not in the reference; its nearest analogue is the 6-id bag with

@@ -106,11 +106,11 @@ def grads(st, ids, dense, labels, dtype=np.float64, storage=None):
     dx0 = np.zeros_like(x0)
     for l in reversed(range(len(st.Wc))):
         du = r(v * x0)
-        dx0 += v * us[l]
+        dx0 += r(v) * us[l]                                     # d x0 is formed from the STORED dx_{l+1} and u_l
         out['cross%d/W' % l] = du.T @ xs[l]
         out['cross%d/b' % l] = du.sum(0)
         v = du @ st.Wc[l].astype(dtype) + r(v)                  # the residual is read back from its stored form
-    dx0 += v
+    dx0 += r(v)
     demb = dx0[:, :st.T * st.dim].reshape(B, st.T, st.dim)
     rows = k['rows']
     flat = rows.reshape(-1)

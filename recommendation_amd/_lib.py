@@ -41,9 +41,8 @@ class FmTable(Structure):
 class GemmEpilogue(Structure):
     """struct mi_gemm_epilogue"""
     _fields_ = [('mode', c_int), ('flags', c_int), ('out', c_void_p), ('ld_out', c_int64), ('bias', c_void_p),
-                ('in0', c_void_p), ('ld_in0', c_int64), ('in1', c_void_p), ('ld_in1', c_int64), ('in2', c_void_p),
-                ('ld_in2', c_int64), ('out1', c_void_p), ('ld_out1', c_int64), ('facc', c_void_p),
-                ('ld_facc', c_int64)]
+                ('in0', c_void_p), ('ld_in0', c_int64), ('in1', c_void_p), ('ld_in1', c_int64),
+                ('out1', c_void_p), ('ld_out1', c_int64)]
 
 
 P = c_void_p
@@ -88,6 +87,7 @@ _SIGNATURES = {
     'mi_head_fwd': (c_int, [P, c_int64, c_int, P, P, P, c_float, c_int64, P, P, P, P]),
     'mi_head_bwd': (c_int, [P, P, P, c_int64, c_int, c_int64, P, c_int64, c_int, P, c_int64, P]),
     'mi_cast_bf16': (c_int, [P, c_int64, P, P]),
+    'mi_cross_input_grad': (c_int, [P, P, c_int, c_int64, c_int, c_int64, P, c_int64, P]),
     'mi_din_lau_build': (c_int, [P, c_int64, c_int, P, P, c_int, P, c_int64, c_int, P, P, P, c_int64, P, P]),
     'mi_din_lau_pool': (c_int, [P, P, P, c_int64, c_int, c_int, P, c_int64, P]),
     'mi_din_lau_pool_bwd': (c_int, [P, P, c_int64, P, c_int64, c_int, c_int, P, P]),

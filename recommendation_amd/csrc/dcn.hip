@@ -241,6 +241,33 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   *reinterpret_cast<ushort4*>(out + i) = u;
 }
 
+struct CrossPtrs {
+  const unsigned short* dx[9];
+  const unsigned short* u[8];
+};
+
+// out = dx[0] + sum_l dx[l+1] * u[l], thread per 4 columns, l ascending
+__global__ __launch_bounds__(256) void cross_input_grad_kernel(CrossPtrs p, int L, int64_t M, int N, int64_t ld,
+                                                              float* __restrict__ out, int64_t ld_out) {
+  const int nq = N / 4;
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * nq) return;
+  const int64_t m = i / nq;
+  const int n = (int) (i - m * nq) * 4;
+  const int64_t off = m * ld + n;
+  auto ld4 = [&](const unsigned short* q) {
+    const ushort4 v = *reinterpret_cast<const ushort4*>(q + off);
+    return make_float4(mi_bf2f(v.x), mi_bf2f(v.y), mi_bf2f(v.z), mi_bf2f(v.w));
+  };
+  float4 acc = ld4(p.dx[0]);
+  for (int l = 0; l < L; ++l) {
+    const float4 d = ld4(p.dx[l + 1]), uu = ld4(p.u[l]);
+    acc.x = fmaf(d.x, uu.x, acc.x); acc.y = fmaf(d.y, uu.y, acc.y);
+    acc.z = fmaf(d.z, uu.z, acc.z); acc.w = fmaf(d.w, uu.w, acc.w);
+  }
+  *reinterpret_cast<float4*>(out + m * ld_out + n) = acc;
+}
+
 bool a16(const void* p) { return ((uintptr_t) p & 15) == 0; }
 bool a8(const void* p) { return ((uintptr_t) p & 7) == 0; }
 
@@ -319,6 +346,26 @@ extern "C" int mi_cast_bf16(const float* in, int64_t n, void* out, void* stream)
   MI_REQUIRE(in && out && n >= 4 && n % 4 == 0 && a16(in) && a8(out), "mi_cast_bf16: bad arguments");
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned) mi_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t) stream, in, n,
                      (unsigned short*) out);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_cross_input_grad(const void* const* dx, const void* const* u, int L, int64_t M, int N, int64_t ld,
+                                   float* out, int64_t ld_out, void* stream) {
+  MI_REQUIRE(dx && out && L >= 0 && L <= 8 && (L == 0 || u) && M >= 1 && N >= 4 && N % 4 == 0 && ld % 4 == 0 &&
+                 ld_out % 4 == 0 && ld >= N && ld_out >= N && a16(out),
+             "mi_cross_input_grad: bad arguments");
+  CrossPtrs p;
+  for (int l = 0; l <= L; ++l) {
+    MI_REQUIRE(dx[l] && a8(dx[l]), "mi_cross_input_grad: dx[%d] null or misaligned", l);
+    p.dx[l] = (const unsigned short*) dx[l];
+  }
+  for (int l = 0; l < L; ++l) {
+    MI_REQUIRE(u[l] && a8(u[l]), "mi_cross_input_grad: u[%d] null or misaligned", l);
+    p.u[l] = (const unsigned short*) u[l];
+  }
+  hipLaunchKernelGGL(cross_input_grad_kernel, dim3((unsigned) mi_cdiv(M * (N / 4), 256)), dim3(256), 0,
+                     (hipStream_t) stream, p, L, M, N, ld, out, ld_out);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

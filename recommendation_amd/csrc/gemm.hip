@@ -124,9 +124,42 @@ __device__ __forceinline__ void st_bf4(void* p, int64_t ld, int64_t m, int64_t n
   *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(p) + m * ld + n) = u;
 }
 
-// what happens to C[m][n..n+3] (n % 4 == 0, all four in range)
-__device__ __forceinline__ void epilogue(const mi_gemm_epilogue& e, int64_t M, int64_t N, int z, int64_t m, int64_t n,
-                                         float4 v) {
+// The epilogue of C[m][n..n+3] (n % 4 == 0, all four in range) in two steps, so that the global
+// loads it needs can be issued for many positions at once, ahead of the arithmetic:
+// epi_load fetches the bf16 inputs of a position, epi_apply consumes them with the accumulator.
+struct EpiIn {
+  ushort4 p0, p1;
+};
+__device__ __forceinline__ float4 bf4(ushort4 u) {
+  return make_float4(mi_bf2f(u.x), mi_bf2f(u.y), mi_bf2f(u.z), mi_bf2f(u.w));
+}
+__device__ __forceinline__ ushort4 ld_u4(const void* p, int64_t ld, int64_t m, int64_t n) {
+  return *reinterpret_cast<const ushort4*>(reinterpret_cast<const unsigned short*>(p) + m * ld + n);
+}
+
+__device__ __forceinline__ EpiIn epi_load(const mi_gemm_epilogue& e, int64_t m, int64_t n) {
+  EpiIn r;
+  r.p0 = r.p1 = make_ushort4(0, 0, 0, 0);
+  switch (e.mode) {
+    case MI_EPI_CROSS_FWD:
+      r.p0 = ld_u4(e.in0, e.ld_in0, m, n);
+      r.p1 = ld_u4(e.in1, e.ld_in1, m, n);
+      break;
+    case MI_EPI_MASK:
+      if (e.in0) r.p0 = ld_u4(e.in0, e.ld_in0, m, n);
+      break;
+    case MI_EPI_CROSS_BWD:
+      if (e.out1) r.p0 = ld_u4(e.in0, e.ld_in0, m, n);
+      if (e.in1) r.p1 = ld_u4(e.in1, e.ld_in1, m, n);
+      break;
+    default:
+      break;
+  }
+  return r;
+}
+
+__device__ __forceinline__ void epi_apply(const mi_gemm_epilogue& e, int64_t M, int z, int64_t m, int64_t n, float4 v,
+                                          const EpiIn& in, float4 bias) {
   switch (e.mode) {
     case MI_EPI_SLAB: {  // fp32 partial of K-slice z
       float* o = reinterpret_cast<float*>(e.out) + ((int64_t) z * M + m) * e.ld_out + n;
@@ -134,10 +167,7 @@ __device__ __forceinline__ void epilogue(const mi_gemm_epilogue& e, int64_t M, i
       break;
     }
     case MI_EPI_BIAS_ACT: {  // out = act(acc + bias)
-      if (e.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-      }
+      v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
       if (e.flags & MI_EPI_RELU) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
@@ -145,42 +175,32 @@ __device__ __forceinline__ void epilogue(const mi_gemm_epilogue& e, int64_t M, i
       break;
     }
     case MI_EPI_CROSS_FWD: {  // u = acc + bias -> out1;  out = in0 (x0) * u + in1 (x_l)
-      const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
       if (e.out1) st_bf4(e.out1, e.ld_out1, m, n, v);
-      const float4 x0 = ld_bf4(e.in0, e.ld_in0, m, n), xl = ld_bf4(e.in1, e.ld_in1, m, n);
+      const float4 x0 = bf4(in.p0), xl = bf4(in.p1);
       st_bf4(e.out, e.ld_out, m, n,
              make_float4(fmaf(x0.x, v.x, xl.x), fmaf(x0.y, v.y, xl.y), fmaf(x0.z, v.z, xl.z), fmaf(x0.w, v.w, xl.w)));
       break;
     }
     case MI_EPI_MASK: {  // out = acc where in0 > 0 else 0 (ReLU backward of the layer that produced in0)
       if (e.in0) {
-        const float4 h = ld_bf4(e.in0, e.ld_in0, m, n);
+        const float4 h = bf4(in.p0);
         v.x = h.x > 0.f ? v.x : 0.f; v.y = h.y > 0.f ? v.y : 0.f;
         v.z = h.z > 0.f ? v.z : 0.f; v.w = h.w > 0.f ? v.w : 0.f;
       }
       st_bf4(e.out, e.ld_out, m, n, v);
       break;
     }
-    case MI_EPI_CROSS_BWD: {
-      // v = acc + in1 (dx_{l+1}, optional) is dx_l -> out.  With out1: out1 = v * in0 (x0) is du_{l-1}
-      // and facc (d x0, fp32) gains v * in2 (u_{l-1}); without out1 (l == 0) facc gains v itself.
+    case MI_EPI_CROSS_BWD: {  // v = acc + in1 (dx_{l+1}, optional) is dx_l -> out;  out1 = v * in0 (x0) is du_{l-1}
       if (e.in1) {
-        const float4 r = ld_bf4(e.in1, e.ld_in1, m, n);
+        const float4 r = bf4(in.p1);
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
       }
-      if (e.out) st_bf4(e.out, e.ld_out, m, n, v);
-      float* fa = e.facc + m * e.ld_facc + n;
-      float4 acc = (e.flags & MI_EPI_INIT) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(fa);
+      st_bf4(e.out, e.ld_out, m, n, v);
       if (e.out1) {
-        const float4 x0 = ld_bf4(e.in0, e.ld_in0, m, n), u = ld_bf4(e.in2, e.ld_in2, m, n);
+        const float4 x0 = bf4(in.p0);
         st_bf4(e.out1, e.ld_out1, m, n, make_float4(v.x * x0.x, v.y * x0.y, v.z * x0.z, v.w * x0.w));
-        acc.x = fmaf(v.x, u.x, acc.x); acc.y = fmaf(v.y, u.y, acc.y);
-        acc.z = fmaf(v.z, u.z, acc.z); acc.w = fmaf(v.w, u.w, acc.w);
-      } else {
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
-      *reinterpret_cast<float4*>(fa) = acc;
       break;
     }
     default:
@@ -297,13 +317,47 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_bf16_kernel(GemmArgs a) {
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
 #undef STAGE
+  // Epilogue.  In the accumulators a lane holds 4 consecutive n of ONE row m, and the 16 lanes of a
+  // group hold 16 different rows: stored like that, every instruction touches 16 rows with 32 bytes
+  // each.  Each fragment row (16 x 16*FN results) is therefore passed through a wave-private
+  // piece of the (now idle) staging LDS and read back with 16 lanes along a row, so that a global
+  // instruction covers 4 rows of 64 consecutive results (128 or 256 contiguous bytes per row) instead.
+  static_assert(FN == 4, "the epilogue transposes 16 x 64 blocks");
+  constexpr int EP_ROW = 64 * 4 + 16;  // bytes of one row of 64 floats, padded against bank conflicts
+  __builtin_amdgcn_s_barrier();        // every wave is done with the staging buffers
+  char* const scratch = smem + w * (16 * EP_ROW);
+  const int64_t n = n0 + wc * FN * 16 + (lane & 15) * 4;
+  const bool n_ok = n < a.N;
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n_ok && a.e.bias && (a.e.mode == MI_EPI_BIAS_ACT || a.e.mode == MI_EPI_CROSS_FWD))
+    bias = *reinterpret_cast<const float4*>(a.e.bias + n);
+  // four fragment rows at a time: all their input loads first (one memory latency for the lot,
+  // not one per row), then transpose + arithmetic + stores
+  constexpr int CH = 4;
+  static_assert(FM % CH == 0, "wave tile");
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int64_t m = m0 + (wr * FM + i) * 16 + (lane & 15);
+  for (int i0 = 0; i0 < FM; i0 += CH) {
+    EpiIn in[CH][4];
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int64_t n = n0 + (wc * FN + j) * 16 + (lane >> 4) * 4;
-      if (m < a.M && n < a.N) epilogue(a.e, a.M, a.N, z, m, n, make_float4(acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w));
+    for (int ii = 0; ii < CH; ++ii)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t m = m0 + (wr * FM + i0 + ii) * 16 + q * 4 + (lane >> 4);
+        if (m < a.M && n_ok) in[ii][q] = epi_load(a.e, m, n);
+      }
+#pragma unroll
+    for (int ii = 0; ii < CH; ++ii) {
+      const int i = i0 + ii;
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        *reinterpret_cast<f4v*>(scratch + (lane & 15) * EP_ROW + (j * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = q * 4 + (lane >> 4);
+        const f4v v = *reinterpret_cast<const f4v*>(scratch + row * EP_ROW + (lane & 15) * 16);
+        const int64_t m = m0 + (wr * FM + i) * 16 + row;
+        if (m < a.M && n_ok) epi_apply(a.e, a.M, z, m, n, make_float4(v.x, v.y, v.z, v.w), in[ii][q], bias);
+      }
     }
   }
 }
@@ -376,9 +430,8 @@ extern "C" int mi_gemm_bf16(int a_reduction_major, int b_reduction_major, int64_
       MI_REQUIRE(e.out && bf_ok(e.out, e.ld_out) && bf_ok(e.in0, e.ld_in0), "%s: mask epilogue", who);
       break;
     case MI_EPI_CROSS_BWD:
-      MI_REQUIRE(e.facc && al16p(e.facc) && e.ld_facc % 4 == 0 && bf_ok(e.out, e.ld_out) && bf_ok(e.in1, e.ld_in1) &&
-                     (!e.out1 || (e.in0 && e.in2 && bf_ok(e.out1, e.ld_out1) && bf_ok(e.in0, e.ld_in0) &&
-                                  bf_ok(e.in2, e.ld_in2))),
+      MI_REQUIRE(e.out && bf_ok(e.out, e.ld_out) && bf_ok(e.in1, e.ld_in1) &&
+                     (!e.out1 || (e.in0 && bf_ok(e.out1, e.ld_out1) && bf_ok(e.in0, e.ld_in0))),
                  "%s: cross-backward epilogue", who);
       break;
     default:

@@ -141,7 +141,7 @@ class DCNv2(object):
         self.u = [torch.empty((B, dp), **bf) for _ in range(self.n_cross)]
         self.h = [torch.empty((B, w), **bf) for w in self.mlp]
         self.dz = [torch.empty((B, w), **bf) for w in self.mlp]
-        self.dx = [torch.empty((B, dp), **bf) for _ in range(2)]
+        self.dx = [torch.empty((B, dp), **bf) for _ in range(self.n_cross + 1)]     # dx[l] = dL/dx_l
         self.du = [torch.empty((B, dp), **bf) for _ in range(2)]
         self.dx0 = torch.empty((B, dp), **f32)
         self.logit, self.loss_rows, self.g = (torch.empty((B,), **f32) for _ in range(3))
@@ -216,26 +216,27 @@ class DCNv2(object):
             if i > 0:
                 ops.gemm_bf16(dz, self.Wm[i].h, ops.MI_EPI_MASK, b_rm=True, out=self.dz[i - 1], in0=self.h[i - 1])
             else:
-                # into the cross network: dx_L, du_{L-1} = dx_L * x0 and d x0 = dx_L * u_{L-1}
+                # into the cross network: dx_L and du_{L-1} = dx_L * x0
                 L = self.n_cross
                 if L:
-                    ops.gemm_bf16(dz, self.Wm[0].h, ops.MI_EPI_CROSS_BWD, b_rm=True, flags=ops.MI_EPI_INIT,
-                                  out=self.dx[L & 1], out1=self.du[L & 1], in0=x0, in2=self.u[L - 1], facc=self.dx0)
+                    ops.gemm_bf16(dz, self.Wm[0].h, ops.MI_EPI_CROSS_BWD, b_rm=True, out=self.dx[L], out1=self.du[L & 1],
+                                  in0=x0)
                 else:
-                    self.dx0.zero_()
-                    ops.gemm_bf16(dz, self.Wm[0].h, ops.MI_EPI_CROSS_BWD, b_rm=True, facc=self.dx0)
+                    ops.gemm_bf16(dz, self.Wm[0].h, ops.MI_EPI_CROSS_BWD, b_rm=True, out=self.dx[0])
             self._weight_step(self.Wm[i], dz, inp)
             self._bias_step(self.bm[i], dz)
-        # cross layers, last first
+        # cross layers, last first: dx_l = du_l W_l + dx_{l+1}, du_{l-1} = dx_l * x0
         for l in reversed(range(self.n_cross)):
-            du, dxn = self.du[(l + 1) & 1], self.dx[(l + 1) & 1]
+            du = self.du[(l + 1) & 1]
             if l > 0:
-                ops.gemm_bf16(du, self.Wc[l].h, ops.MI_EPI_CROSS_BWD, b_rm=True, out=self.dx[l & 1], in1=dxn,
-                              out1=self.du[l & 1], in0=x0, in2=self.u[l - 1], facc=self.dx0)
+                ops.gemm_bf16(du, self.Wc[l].h, ops.MI_EPI_CROSS_BWD, b_rm=True, out=self.dx[l], in1=self.dx[l + 1],
+                              out1=self.du[l & 1], in0=x0)
             else:
-                ops.gemm_bf16(du, self.Wc[0].h, ops.MI_EPI_CROSS_BWD, b_rm=True, in1=dxn, facc=self.dx0)
+                ops.gemm_bf16(du, self.Wc[0].h, ops.MI_EPI_CROSS_BWD, b_rm=True, out=self.dx[0], in1=self.dx[1])
             self._weight_step(self.Wc[l], du, self.x[l])
             self._bias_step(self.bc[l], du)
+        # d x0 = dx_0 + sum_l dx_{l+1} * u_l, one pass over the stored tensors
+        ops.cross_input_grad(self.dx, self.u, self.dx0)
         # embeddings: sort by row, sum each row's gradients in a fixed order, row-wise Adagrad
         self.plan.prepare(ids)
         ops.bwd_apply_adagrad_rowwise(self.plan, self.dx0, self.V, self.V_acc, self.emb_lr, self.emb_eps,

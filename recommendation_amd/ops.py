@@ -518,7 +518,7 @@ def fm_dense_step_rows(X, dim, n_dense, dp, dm, dv, lr_t, beta1, beta2, eps, los
 
 # ----------------------------------------------------------------------------- bf16 MFMA contractions
 MI_EPI_SLAB, MI_EPI_BIAS_ACT, MI_EPI_CROSS_FWD, MI_EPI_MASK, MI_EPI_CROSS_BWD = 0, 1, 2, 3, 4
-MI_EPI_RELU, MI_EPI_INIT = 1, 2
+MI_EPI_RELU = 1
 
 
 def _ld(t):
@@ -526,14 +526,14 @@ def _ld(t):
 
 
 def gemm_bf16(A, B, mode, M=None, N=None, K=None, a_rm=False, b_rm=False, k_splits=1, flags=0, out=None, bias=None,
-              in0=None, in1=None, in2=None, out1=None, facc=None):
+              in0=None, in1=None, out1=None):
     """C[m][n] = sum_k A(m,k) B(n,k) on the matrix cores, then the epilogue ``mode`` (MI_EPI_*).
     A is [M][K] (or [K][M] with ``a_rm``), B is [N][K] (or [K][N] with ``b_rm``), both bf16 with
     contiguous rows; M, N, K default to the tensors' shapes (pass them to use a sub-block).  All
     epilogue tensors are 2-D with contiguous rows: bf16 except ``out`` under MI_EPI_SLAB
-    ([k_splits, M, N] fp32), ``bias`` [N] fp32 and ``facc`` fp32."""
-    _need_cuda(A, B, out, bias, in0, in1, in2, out1, facc)
-    for t in (A, B, in0, in1, in2, out1):
+    ([k_splits, M, N] fp32) and ``bias`` [N] fp32."""
+    _need_cuda(A, B, out, bias, in0, in1, out1)
+    for t in (A, B, in0, in1, out1):
         if t is not None and (t.dtype != torch.bfloat16 or t.stride(-1) != 1):
             raise MiError("gemm_bf16: operands and bf16 epilogue tensors must be bf16 with contiguous rows")
     if M is None:
@@ -543,8 +543,8 @@ def gemm_bf16(A, B, mode, M=None, N=None, K=None, a_rm=False, b_rm=False, k_spli
     if N is None:
         N = B.shape[1] if b_rm else B.shape[0]
     e = _lib.GemmEpilogue(mode=mode, flags=flags, out=_p(out), ld_out=out.stride(-2) if out is not None else 0,
-                          bias=_p(bias), in0=_p(in0), ld_in0=_ld(in0), in1=_p(in1), ld_in1=_ld(in1), in2=_p(in2),
-                          ld_in2=_ld(in2), out1=_p(out1), ld_out1=_ld(out1), facc=_p(facc), ld_facc=_ld(facc))
+                          bias=_p(bias), in0=_p(in0), ld_in0=_ld(in0), in1=_p(in1), ld_in1=_ld(in1),
+                          out1=_p(out1), ld_out1=_ld(out1))
     _lib.call('mi_gemm_bf16', int(a_rm), int(b_rm), M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), k_splits,
               ctypes.byref(e), _stream())
     return out
@@ -574,6 +574,18 @@ def head_fwd(h, w, bias, labels, gscale, logit, loss_rows, g):
 def head_bwd(g, w, h, dh, slices, partial):
     _lib.call('mi_head_bwd', _p(g), _p(w), _p(h), h.stride(0), h.shape[1], h.shape[0], _p(dh), dh.stride(0), slices,
               _p(partial), partial.stride(0), _stream())
+
+
+def cross_input_grad(dx, u, out, N=None):
+    """out (fp32) = dx[0] + sum_l dx[l+1]*u[l]; dx: L+1 bf16 tensors [M, ld], u: L of them."""
+    L = len(u)
+    if len(dx) != L + 1:
+        raise MiError("cross_input_grad: need one more dx than u")
+    P = ctypes.c_void_p * 9
+    pdx = P(*([t.data_ptr() for t in dx] + [None] * (8 - L)))
+    pu = P(*([t.data_ptr() for t in u] + [None] * (9 - L)))
+    _lib.call('mi_cross_input_grad', pdx, pu, L, dx[0].shape[0], N or dx[0].shape[1], dx[0].stride(0), _p(out),
+              out.stride(0), _stream())
 
 
 def cast_bf16(src, dst):

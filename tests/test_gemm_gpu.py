@@ -101,19 +101,30 @@ def test_mask_and_cross_backward_epilogues(dev):
     ops.gemm_bf16(dY, W, ops.MI_EPI_MASK, b_rm=True, out=out, in0=H)
     want = (dY.float() @ W.float()) * (H.float() > 0)
     assert torch.equal(out.float(), want.to(torch.bfloat16).float())
-    # cross backward: v = C + R; out = v; out1 = v*x0; facc = (init) v*u, then += on a second call
-    R, x0, u = _ints((M, N), dev, 7), _ints((M, N), dev, 8), _ints((M, N), dev, 9)
+    # cross backward: v = C + R; out = v; out1 = v*x0
+    R, x0 = _ints((M, N), dev, 7), _ints((M, N), dev, 8)
     dx = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
     du = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-    facc = torch.full((M, N), float('nan'), dtype=torch.float32, device=dev)
-    ops.gemm_bf16(dY, W, ops.MI_EPI_CROSS_BWD, b_rm=True, flags=ops.MI_EPI_INIT, out=dx, in1=R, in0=x0, in2=u,
-                  out1=du, facc=facc)
+    ops.gemm_bf16(dY, W, ops.MI_EPI_CROSS_BWD, b_rm=True, out=dx, in1=R, in0=x0, out1=du)
     v = dY.float() @ W.float() + R.float()
     assert torch.equal(dx.float(), v.to(torch.bfloat16).float())
     assert torch.equal(du.float(), (v * x0.float()).to(torch.bfloat16).float())
-    assert torch.equal(facc, v * u.float())
-    ops.gemm_bf16(dY, W, ops.MI_EPI_CROSS_BWD, b_rm=True, out=None, in1=R, facc=facc)
-    assert torch.equal(facc, v * u.float() + v)
+    dx2 = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm_bf16(dY, W, ops.MI_EPI_CROSS_BWD, b_rm=True, out=dx2)
+    assert torch.equal(dx2.float(), (dY.float() @ W.float()).to(torch.bfloat16).float())
+
+
+def test_cross_input_grad(dev):
+    from recommendation_amd import ops
+    M, N, L = 300, 448, 3
+    dx = [_ints((M, N), dev, 20 + l) for l in range(L + 1)]
+    u = [_ints((M, N), dev, 30 + l) for l in range(L)]
+    out = torch.full((M, N), float('nan'), dtype=torch.float32, device=dev)
+    ops.cross_input_grad(dx, u, out)
+    want = dx[0].float()
+    for l in range(L):
+        want = want + dx[l + 1].float() * u[l].float()
+    assert torch.equal(out, want)
 
 
 def test_rejects_bad_shapes(dev):
