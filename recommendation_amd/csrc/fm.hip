@@ -36,16 +36,18 @@ __global__ __launch_bounds__(256) void fm_fwd_kernel(FmFwdArgs a) {
 // schedule (its consumers run in later launches).  The two halves do not depend on each other, so
 // the launch lasts as long as the longer one instead of their sum.
 template <typename IDX, int DIM>
-__global__ __launch_bounds__(TS_THREADS) void fm_fwd_sort_kernel(FmFwdArgs a, int bag_len_one_n, uint32_t sentinel,
+__global__ __launch_bounds__(TS_THREADS) void fm_fwd_sort_kernel(FmFwdArgs a, int parts, uint32_t sentinel,
                                                                 uint32_t* __restrict__ sorted_rows,
                                                                 uint32_t* __restrict__ perm, float* __restrict__ sched,
                                                                 float lr, float b1, float b2) {
-  if ((int) blockIdx.x < a.T) {
-    table_sort_body<IDX>(blockIdx.x, a.toffs, a.T, a.ids, 1, bag_len_one_n, sentinel, sorted_rows, perm);
+  const int sort_blocks = a.T * parts;
+  if ((int) blockIdx.x < sort_blocks) {
+    table_sort_body<IDX>(blockIdx.x / parts, blockIdx.x % parts, parts, a.toffs, a.T, a.ids, 1, a.B, sentinel,
+                         sorted_rows, perm);
     return;
   }
-  if (sched && (int) blockIdx.x == a.T && threadIdx.x == 0) adam_schedule_body(sched, lr, b1, b2);
-  fm_fwd_body<IDX, DIM>(a, blockIdx.x - a.T, TS_THREADS);
+  if (sched && (int) blockIdx.x == sort_blocks && threadIdx.x == 0) adam_schedule_body(sched, lr, b1, b2);
+  fm_fwd_body<IDX, DIM>(a, blockIdx.x - sort_blocks, TS_THREADS);
 }
 
 __global__ __launch_bounds__(FM_DENSE_THREADS) void fm_dense_kernel(FmDenseArgs a) {
@@ -68,9 +70,12 @@ int launch_fm(const FmFwdArgs& a, uint32_t sentinel, uint32_t* sorted_rows, uint
     constexpr int G_ = (D / 4) > 16 ? (D / 4) : 16;                                                                 \
     if (!sorted_rows)                                                                                               \
       hipLaunchKernelGGL((fm_fwd_kernel<IDX, D>), dim3((unsigned) mi_cdiv(a.B, 256 / G_)), dim3(256), 0, s, a);     \
-    else                                                                                                            \
-      hipLaunchKernelGGL((fm_fwd_sort_kernel<IDX, D>), dim3((unsigned) (a.T + mi_cdiv(a.B, TS_THREADS / G_))),      \
-                         dim3(TS_THREADS), 0, s, a, a.B, sentinel, sorted_rows, perm, sched, lr, b1, b2);           \
+    else {                                                                                                          \
+      const int fwd_blocks_ = (int) mi_cdiv(a.B, TS_THREADS / G_);                                                  \
+      const int parts_ = mi_table_sort_parts(a.T, a.B, fwd_blocks_);                                                \
+      hipLaunchKernelGGL((fm_fwd_sort_kernel<IDX, D>), dim3((unsigned) (a.T * parts_ + fwd_blocks_)),               \
+                         dim3(TS_THREADS), 0, s, a, parts_, sentinel, sorted_rows, perm, sched, lr, b1, b2);        \
+    }                                                                                                               \
     break;                                                                                                          \
   }
   switch (a.tab.dim) {

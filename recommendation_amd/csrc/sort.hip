@@ -400,10 +400,11 @@ namespace {
 template <typename IDX>
 __global__ __launch_bounds__(TS_THREADS) void table_sort_kernel(const int64_t* __restrict__ toffs, int T,
                                                                const void* __restrict__ indices, int bag_len,
-                                                               int n, uint32_t sentinel,
+                                                               int n, int parts, uint32_t sentinel,
                                                                uint32_t* __restrict__ sorted_rows,
                                                                uint32_t* __restrict__ perm) {
-  table_sort_body<IDX>(blockIdx.x, toffs, T, indices, bag_len, n, sentinel, sorted_rows, perm);
+  table_sort_body<IDX>(blockIdx.x / parts, blockIdx.x % parts, parts, toffs, T, indices, bag_len, n, sentinel,
+                       sorted_rows, perm);
 }
 
 int bit_width_u64(uint64_t v) {
@@ -467,12 +468,13 @@ extern "C" int mi_embag_bwd_prepare(const int64_t* table_offsets, int T, int64_t
     // fixed-width bags, few enough entries per table: one launch, every table sorted in LDS.
     // (Only without run arrays: padding entries then end each table's block, not the array.)
     const int per_table = n / T;
+    const int parts = mi_table_sort_parts(T, per_table, 0);
     if (idx_bits == 32)
-      hipLaunchKernelGGL(table_sort_kernel<int32_t>, dim3(T), dim3(TS_THREADS), 0, s, table_offsets, T, indices,
-                         bag_len, per_table, sentinel, sorted_rows, reinterpret_cast<uint32_t*>(perm));
+      hipLaunchKernelGGL(table_sort_kernel<int32_t>, dim3(T * parts), dim3(TS_THREADS), 0, s, table_offsets, T,
+                         indices, bag_len, per_table, parts, sentinel, sorted_rows, reinterpret_cast<uint32_t*>(perm));
     else
-      hipLaunchKernelGGL(table_sort_kernel<int64_t>, dim3(T), dim3(TS_THREADS), 0, s, table_offsets, T, indices,
-                         bag_len, per_table, sentinel, sorted_rows, reinterpret_cast<uint32_t*>(perm));
+      hipLaunchKernelGGL(table_sort_kernel<int64_t>, dim3(T * parts), dim3(TS_THREADS), 0, s, table_offsets, T,
+                         indices, bag_len, per_table, parts, sentinel, sorted_rows, reinterpret_cast<uint32_t*>(perm));
     MI_LAUNCH_CHECK();
     return MI_OK;
   }
