@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Two rocprofv3 counter_collection.csv files (one --pmc FETCH_SIZE pass, one --pmc WRITE_SIZE pass of the
+same command) -> the per-kernel HBM traffic JSON that bench.py reads for roofline.traffic.
+usage: pmc_json.py fetch.csv write.csv > profiles/<name>_pmc.json"""
+import csv
+import json
+import re
+import statistics
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.findall(r'(\w+_kernel)', name)
+    s = m[0] if m else None
+    if s == 'seg_sorted_kernel' and 'FmDenseExtra' in name:
+        s += ' +dense'
+    return s
+
+
+def collect(path, counter):
+    by = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter:
+            continue
+        s = short(r['Kernel_Name'])
+        if s:
+            by[s].append(float(r['Counter_Value']))
+    return by
+
+
+fetch = collect(sys.argv[1], 'FETCH_SIZE')
+write = collect(sys.argv[2], 'WRITE_SIZE')
+cmd = "rocprofv3 --pmc %s --output-format csv -d out -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 --stage-reps 5"
+out = {
+    "what": "HBM traffic per launch from rocprofv3 PMC counters, FM bench (batch 8192, Adam), MI355X",
+    "commands": [cmd % "FETCH_SIZE", cmd % "WRITE_SIZE"],
+    "corrections": "FETCH_SIZE and WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, "
+                   "so it is doubled (MI355X_MICROARCH, HBM section); WRITE_SIZE is taken as is. hbm_bytes_per_launch = "
+                   "2*1024*FETCH_SIZE + 1024*WRITE_SIZE, medians over the launches of a kernel.",
+    "workload": "fm_criteo_26x16_b8192",
+    "kernels": {},
+}
+for k in fetch:
+    if k not in write:
+        continue
+    f = statistics.median(fetch[k])
+    w = statistics.median(write[k])
+    out["kernels"][k] = {"launches": len(fetch[k]), "fetch_size_kb_median": f, "write_size_kb_median": w,
+                         "hbm_bytes_per_launch": int(2 * 1024 * f + 1024 * w)}
+print(json.dumps(out, indent=1))
