@@ -318,25 +318,35 @@ int mi_adam_schedule_step(float* sched, float lr, float beta1, float beta2, void
  *   all-to-all  send[N][blk] int32            requester -> owner   blk = mi_shard_block_ints(B,T)
  *   all-to-all  partial[N][B][dim+2] fp32      owner -> requester
  *   all-gather  X[B][ld] fp32 -> X_all[N*B][ld]
+ * and a step is four launches: route, owner forward + sort, combine, owner backward + dense side.
  * ---------------------------------------------------------------------------------- */
 
-/* Ints per rank pair in the row exchange: B+1 offsets followed by room for B*T rows. */
+/* Ints per rank pair in the row exchange: ceil(B/64)*T chunk counts, then one slot per
+ * (table, sample). */
 int64_t mi_shard_block_ints(int64_t B, int T);
 
-/* Requester: route the ids of a batch [B][T].  send[N][blk]: block d holds, for destination
- * rank d, bag_off[0..B] (exclusive offsets of each sample's entries; [B] = their number)
- * followed by the local rows grouped by sample, fields in field order. */
+/* Requester: route the ids of a batch [B][T].  Block o of send (for owner o) =
+ *   cnt[c][t]   how many slots of table t in samples [64c, 64c+64) are owner o's
+ *   slot[t][b]  the local row of (b, t) when rank o owns it, -1 otherwise (also for an id outside
+ *               its table, which sets MI_IDERR_RANGE in *err). */
 int mi_shard_route(const int64_t* table_offsets, int T, const void* ids, int idx_bits, int64_t B,
                    int n_ranks, int32_t* send, int32_t* err, void* stream);
 
-/* Owner: recv[N][blk] = the blocks received from every rank.  Writes
- *   partial[N][B][dim+2]  { sum v (dim), sum |v|^2, sum w1 } per (source rank, sample)
- *   rows_out[n]           the received rows back to back (source rank, sample, field order)
- *   entry_sample[n]       s*B + b of every received entry
- *   n_out[0]              n, at most N*B*T (size rows_out / entry_sample for that) */
-int mi_fm_partial_fwd(const mi_fm_table* tab, int64_t local_rows, const int32_t* recv,
-                      int n_ranks, int64_t B, int T, float* partial, int32_t* rows_out,
-                      int32_t* entry_sample, int32_t* n_out, int32_t* err, void* stream);
+/* Owner, ONE launch: recv[N][blk] = the blocks received from every rank.  Writes
+ *   partial[N][B][dim+2]   { sum v (dim), sum |v|^2, sum w1 } per (source rank, sample)
+ *   sorted_rows[n]         the local rows of all valid slots, ascending (tables lie in row order)
+ *   perm[n]                s*B + b of every sorted entry (the row of X_all the backward reads);
+ *                          stable: equal rows keep (s, b) order
+ *   n_total[0]             n <= N*B*T (size sorted_rows / perm for that)
+ * and, when sched != NULL, advances the Adam schedule (see mi_adam_schedule_step).  sorted_rows,
+ * perm and n_total may all be NULL (forward only).  Any id skew is sorted correctly: a table with
+ * more than 8192 entries here is split on further key bits inside the workgroup, only slower.
+ * n_ranks * B < 2^24, T <= 64. */
+int mi_shard_owner_fwd_sort(const mi_fm_table* tab, int64_t local_rows, const int64_t* table_offsets,
+                            int T, int rank, int n_ranks, const int32_t* recv, int64_t B,
+                            float* partial, uint32_t* sorted_rows, int32_t* perm, int32_t* n_total,
+                            float* sched, float lr, float beta1, float beta2, int32_t* err,
+                            void* stream);
 
 /* Requester: partials[N][B][dim+2] (one slab per owner, summed in rank order) + dense part +
  * bias -> one row per sample of what the other ranks need,
@@ -346,11 +356,21 @@ int mi_fm_combine(const float* partials, int n_ranks, int64_t B, int dim, const 
                   int n_dense, const float* wd, const float* bias, const float* labels,
                   float gscale, float* logit, float* X, int ld, void* stream);
 
-/* mi_fm_bwd_apply reading g and S from rows laid out as mi_fm_combine writes them
- * (X_all after the all-gather); entry_sample indexes rows of X. */
-int mi_fm_bwd_apply_rows(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* X, int ld,
-                         const int32_t* entry_sample, int opt, float lr, const float* lr_dev,
-                         float beta1, float beta2, float eps, void* stream);
+/* Owner + replica, ONE launch after the all-gather: the sparse backward with the fused optimizer
+ * over sorted_rows / perm / n_total as mi_shard_owner_fwd_sort wrote them (n_slots = their capacity,
+ * which sizes the launch), reading g and S
+ * from X_all[rows][ld]; and the dense side over ALL rows of X_all: every replica computes the
+ * dense-side gradients of all N*B samples itself, in the same order on every rank, so replicas
+ * stay bit-identical without an all-reduce; TensorFlow-form Adam on dp[n_dense+1] = {wd, bias},
+ * loss_out[0] = mean of the loss column.  scratch: mi_shard_dense_scratch_floats(rows, n_dense)
+ * floats, zeroed once by the caller. */
+int64_t mi_shard_dense_scratch_floats(int64_t rows, int n_dense);
+int mi_shard_owner_bwd_dense(const mi_fm_table* tab, int64_t local_rows, const uint32_t* sorted_rows,
+                             const int32_t* perm, const int32_t* n_total, int64_t n_slots, const float* X, int ld,
+                             int64_t rows, int opt, float lr, const float* lr_dev, float beta1,
+                             float beta2, float eps, int n_dense, float* dp, float* dm, float* dv,
+                             float dense_lr_t, const float* dense_lr_dev, float* scratch,
+                             float* loss_out, void* stream);
 
 /* mi_fm_dense_step over n rows laid out as mi_fm_combine writes them: every replica computes
  * the dense-side gradients of ALL N*B samples itself (same order on every rank, so replicas

@@ -176,6 +176,82 @@ __device__ __forceinline__ void fm_dense_body(const FmDenseArgs& a, int j, float
   }
 }
 
+// The dense side over the rows of a gathered sample matrix X[rows][ld] =
+// [ S (dim) | g | loss | dense (n_dense) | pad ], split over `chunks` workgroups: each reduces its
+// rows for all n_dense+2 columns at once (CT threads across a row, FM_DENSE_THREADS/CT rows in
+// flight; fixed order), leaves a partial in part[chunk][CT], and the workgroup that finishes last
+// adds the partials in chunk order and applies TensorFlow-form Adam / writes the mean loss.  The
+// result depends only on rows and chunks.  *ticket must be 0 before the first call; it is left 0.
+struct FmDenseRowsArgs {
+  const float* X;
+  int64_t ld, rows;
+  int dim, n_dense, chunks, ct;  // ct: power of two >= n_dense + 2, <= FM_DENSE_THREADS
+  float* part;
+  int* ticket;
+  float* dp;
+  float* dm;
+  float* dv;
+  float lr_t;
+  const float* lr_dev;
+  float b1, b2, eps;
+  float* loss_out;
+};
+
+__device__ __forceinline__ void fm_dense_rows_body(const FmDenseRowsArgs& a, int chunk, float* sh) {
+  constexpr int NT = FM_DENSE_THREADS;
+  __shared__ int last;
+  const int ct = a.ct, rl = NT / ct;
+  const int j = threadIdx.x % ct, rr = threadIdx.x / ct;
+  const int64_t per = (a.rows + a.chunks - 1) / a.chunks;
+  const int64_t lo = chunk * per, hi = lo + per < a.rows ? lo + per : a.rows;
+  const int col = j < a.n_dense ? a.dim + 2 + j : (j == a.n_dense ? a.dim : a.dim + 1);
+  float acc = 0.f;
+  if (j < a.n_dense + 2) {
+    // four rows in flight per thread; their terms are added in row order
+    for (int64_t r = lo + rr; r < hi; r += 4 * rl) {
+      float g[4], v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t ru = r + u * rl;
+        const float* x = a.X + (ru < hi ? ru : r) * a.ld;
+        g[u] = x[a.dim];
+        v[u] = x[col];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + u * rl < hi) acc = j < a.n_dense ? fmaf(g[u], v[u], acc) : acc + v[u];
+    }
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = rl / 2; s > 0; s >>= 1) {
+    if (rr < s) sh[threadIdx.x] += sh[threadIdx.x + s * ct];
+    __syncthreads();
+  }
+  if (rr == 0) a.part[(size_t) chunk * ct + j] = sh[j];
+  __threadfence();  // the partial is visible device-wide before the ticket is taken
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(a.ticket, 1) == a.chunks - 1 ? 1 : 0;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if ((int) threadIdx.x < a.n_dense + 2) {
+    const int k = threadIdx.x;
+    float tot = 0.f;
+    for (int c = 0; c < a.chunks; ++c) tot += __builtin_nontemporal_load(a.part + (size_t) c * ct + k);
+    if (k == a.n_dense + 1) {
+      a.loss_out[0] = tot / (float) a.rows;
+    } else {
+      const float mi = a.dm[k] + (tot - a.dm[k]) * (1.0f - a.b1);
+      const float vi = a.dv[k] + (tot * tot - a.dv[k]) * (1.0f - a.b2);
+      a.dm[k] = mi;
+      a.dv[k] = vi;
+      a.dp[k] -= (mi * (a.lr_dev ? a.lr_dev[0] : a.lr_t)) / (sqrtf(vi) + a.eps);
+    }
+  }
+  if (threadIdx.x == 0) atomicExch(a.ticket, 0);
+}
+
 // sched = {alpha_t, beta1_power, beta2_power}: TensorFlow keeps the two powers as fp32 variables
 // on the device and multiplies them by beta once per step; alpha_t is formed from them in fp32.
 // One thread calls this.

@@ -4,178 +4,733 @@
 // (recommendation/code/model_trainer.py:124-136: every variable read and every Adam apply is a
 // gRPC hop to the ps task).  Here the rows of all tables are dealt round-robin over the N ranks
 // (global row r lives on rank r % N as local row r / N) and a step exchanges, per rank pair,
-//   requester -> owner : the local rows it needs, grouped by sample (route_* kernels)
-//   owner -> requester : per SAMPLE partial pools  sum v, sum |v|^2, sum w1  (fm_partial_fwd)
+//   requester -> owner : its [T][B] matrix of local rows, -1 where the row lives elsewhere
+//   owner -> requester : per SAMPLE partial pools  sum v, sum |v|^2, sum w1
 // so the payload coming back is D+2 floats per sample and owner, not D+1 per (sample, field).
-// Nothing here uses float atomics: every sum has a fixed order (fields in field order, owners
-// in rank order), so a sharded run reproduces itself bit for bit.
+// Every buffer has a fixed size and nothing on the host ever waits for a count: the owner finds
+// the entries addressed to it by looking at the slots.  Nothing here uses float atomics: every
+// sum has a fixed order (fields in field order, owners in rank order), so a sharded run
+// reproduces itself bit for bit.
 #include "common.h"
+#include "fm_body.h"
+#include "table_sort.h"
 
 namespace {
 
 constexpr int MAX_RANKS = 16;
+constexpr int ROUTE_SAMPLES = 64;  // samples per workgroup of the route kernel
 
+// Requester: ids [B][T] -> one block per owner o,
+//   block o = [ cnt[c][t] : chunk c = 64 consecutive samples, how many of its slots of table t are o's ]
+//             [ slot[t][b] : the local row of (b, t) when rank o owns it, else -1 ]
+// A workgroup takes one chunk: the ids are read as they lie (sample-major), turned around in LDS and
+// written table-major, so both sides of the transpose are full-line accesses.  The counts let the
+// owner place every chunk's entries without a counting pass of its own.
+constexpr int ROUTE_THREADS = 1024;
 template <typename IDX>
-__device__ __forceinline__ bool route_one(const int64_t* toffs, const void* ids, int T, int b, int f, int N,
-                                          int& dest, int& local) {
-  const int64_t id = mi_ld_id<IDX>(ids, (int64_t) b * T + f);
-  const int64_t base = toffs[f];
-  const int64_t rows = toffs[f + 1] - base;
-  if (id < 0 || id >= rows) return false;
-  const int64_t g = base + id;
-  dest = (int) (g % N);
-  local = (int) (g / N);
-  return true;
-}
-
-// The exchange buffer has one block per rank, all the same size so that the all-to-all needs no
-// size negotiation (and no host synchronisation):
-//   block d = [ bag_off[0..B] | local rows, grouped by sample, fields in field order | unused ]
-// with stride B+1+B*T ints; bag_off[B] is the number of rows in the block.
-
-// thread per sample: how many of its T entries go to each rank -> block[dest][b]
-template <typename IDX>
-__global__ __launch_bounds__(256) void route_count_kernel(const int64_t* __restrict__ toffs, int T,
-                                                         const void* __restrict__ ids, int B, int N, int stride,
-                                                         int32_t* __restrict__ buf, int32_t* __restrict__ err) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  int cnt[MAX_RANKS];
-#pragma unroll
-  for (int r = 0; r < MAX_RANKS; ++r) cnt[r] = 0;
+__global__ __launch_bounds__(ROUTE_THREADS) void route_kernel(const int64_t* __restrict__ toffs, int T,
+                                                   const void* __restrict__ ids, int B, int N, int64_t stride,
+                                                   int32_t* __restrict__ send, int32_t* __restrict__ err) {
+  extern __shared__ int32_t tile[];  // [T][ROUTE_SAMPLES] local row, and the owner behind it
+  int32_t* loc = tile;
+  int32_t* own = tile + T * ROUTE_SAMPLES;
+  const int chunk = blockIdx.x, n_chunks = gridDim.x;
+  const int b0 = chunk * ROUTE_SAMPLES;
+  const int nb = min(ROUTE_SAMPLES, B - b0);
   bool bad = false;
-  for (int f = 0; f < T; ++f) {
-    int dest, local;
-    if (route_one<IDX>(toffs, ids, T, b, f, N, dest, local)) {
-#pragma unroll
-      for (int r = 0; r < MAX_RANKS; ++r) cnt[r] += (r == dest) ? 1 : 0;
+  for (int i = threadIdx.x; i < nb * T; i += ROUTE_THREADS) {
+    const int bl = i / T, t = i - bl * T;
+    const int64_t id = mi_ld_id<IDX>(ids, (int64_t) b0 * T + i);
+    const int64_t base = toffs[t];
+    const int64_t rows = toffs[t + 1] - base;
+    int o = -1, l = -1;
+    if (id >= 0 && id < rows) {
+      const int64_t g = base + id;
+      o = (int) (g % N);
+      l = (int) (g / N);
     } else {
       bad = true;
     }
+    loc[t * ROUTE_SAMPLES + bl] = l;
+    own[t * ROUTE_SAMPLES + bl] = o;
   }
-#pragma unroll
-  for (int r = 0; r < MAX_RANKS; ++r)
-    if (r < N) buf[(size_t) r * stride + b] = cnt[r];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  // a wave per (owner, table) row of 64 slots
+  for (int ot = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); ot < N * T; ot += ROUTE_THREADS / 64) {
+    const int o = ot / T, t = ot - o * T;
+    const bool mine = lane < nb && own[t * ROUTE_SAMPLES + lane] == o;
+    int32_t* blk = send + (size_t) o * stride;
+    if (lane < nb) blk[(size_t) n_chunks * T + (size_t) t * B + b0 + lane] = mine ? loc[t * ROUTE_SAMPLES + lane] : -1;
+    const int cnt = __popcll(__ballot(mine));
+    if (lane == 0) blk[chunk * T + t] = cnt;
+  }
   if (bad && err) atomicOr(err, MI_IDERR_RANGE);
 }
 
-// workgroup per destination rank: exclusive scan of block[dest][0..B) in place (entry [B] = total)
-__global__ __launch_bounds__(256) void route_scan_kernel(int32_t* __restrict__ buf, int B, int stride) {
-  __shared__ int32_t wsum[4];
-  int32_t* row = buf + (size_t) blockIdx.x * stride;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int32_t carry = 0;
-  for (int base = 0; base < B; base += 256) {
-    const int i = base + threadIdx.x;
-    const int32_t v = i < B ? row[i] : 0;
-    int32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int32_t t = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    __syncthreads();
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    int32_t wb = 0;
-    for (int k = 0; k < w; ++k) wb += wsum[k];
-    if (i < B) row[i] = carry + wb + inc - v;
-    carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  }
-  if (threadIdx.x == 0) row[B] = carry;
+// ---- owner side ------------------------------------------------------------------------------
+// Received: recv[s][t][b], the slot of sample b of rank s for table t.  Table t's rows on rank r
+// are the local rows [first_local(t), first_local(t+1)).
+__device__ __forceinline__ int64_t first_local(const int64_t* toffs, int t, int rank, int N) {
+  return (toffs[t] - rank + N - 1) / N;  // toffs[t] >= 0, rank < N: the numerator is never negative
 }
 
-// thread per sample: write its local rows into the blocks
-template <typename IDX>
-__global__ __launch_bounds__(256) void route_fill_kernel(const int64_t* __restrict__ toffs, int T,
-                                                        const void* __restrict__ ids, int B, int N, int stride,
-                                                        int32_t* __restrict__ buf) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  int slot[MAX_RANKS];
-#pragma unroll
-  for (int r = 0; r < MAX_RANKS; ++r) slot[r] = r < N ? r * stride + (B + 1) + buf[(size_t) r * stride + b] : 0;
-  for (int f = 0; f < T; ++f) {
-    int dest, local;
-    if (!route_one<IDX>(toffs, ids, T, b, f, N, dest, local)) continue;
-    int at = 0;
-#pragma unroll
-    for (int r = 0; r < MAX_RANKS; ++r) {
-      if (r == dest) { at = slot[r]; slot[r] += 1; }
-    }
-    buf[at] = local;
-  }
-}
+struct OwnerArgs {
+  mi_fm_table tab;
+  const int64_t* toffs;
+  const int32_t* recv;  // [N] blocks of `stride` ints: cnt[n_chunks][T], then slot[T][B]
+  int64_t stride;
+  int T, B, N, rank, n_chunks;
+  __device__ __forceinline__ const int32_t* cnt(int s) const { return recv + (size_t) s * stride; }
+  __device__ __forceinline__ const int32_t* slots(int s) const { return recv + (size_t) s * stride + (size_t) n_chunks * T; }
+  float* partial;
+  int32_t* err;
+};
 
-// Owner side.  Bag (src, b) = rows [bag_off[b], bag_off[b+1]) of received block src.
-// One lane group (DIM/4 lanes) per bag: partial[src][b] = { sum v (DIM), sum |v|^2, sum w1 }.
-// The rows are also written out back to back over all blocks (rows_out, what the backward's sort
-// takes) with entry_sample[entry] = src*B + b, and n_out[0] = their number.  Empty bag -> zeros.
+// Forward of the bags of virtual workgroup `vblock`: bag (s, b) = the valid slots recv[s][*][b];
+// partial[s][b] = { sum v (DIM), sum |v|^2, sum w1 }, zeros for a bag without rows here.  Same lane
+// mapping as the single-GPU forward: G lanes per bag, FP fields in flight.
 template <int DIM>
-__global__ __launch_bounds__(256) void fm_partial_fwd_kernel(mi_fm_table tab, const int32_t* __restrict__ recv,
-                                                            int stride, int N, int B, int64_t local_rows,
-                                                            float* __restrict__ partial,
-                                                            int32_t* __restrict__ rows_out,
-                                                            int32_t* __restrict__ entry_sample,
-                                                            int32_t* __restrict__ n_out, int32_t* __restrict__ err) {
+__device__ __forceinline__ void owner_fwd_body(const OwnerArgs& a, int vblock, int nthreads, const int32_t* lo_tab) {
   constexpr int CH = DIM / 4;
-  const int bag = blockIdx.x * (256 / CH) + threadIdx.x / CH;
-  if (bag >= N * B) return;
-  const int c = threadIdx.x % CH;
-  const int src = bag / B, b = bag - src * B;
-  const int32_t* blk = recv + (size_t) src * stride;
-  int cbase = 0, total = 0;
-  for (int r = 0; r < N; ++r) {
-    const int cnt = recv[(size_t) r * stride + B];
-    if (r < src) cbase += cnt;
-    total += cnt;
-  }
-  if (bag == 0 && c == 0) n_out[0] = total;
-  const int beg = blk[b], end = blk[b + 1];
-  const int32_t* rows = blk + (B + 1);
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  float q = 0.f, lin = 0.f;
-  bool bad = beg < 0 || end < beg || end > stride - (B + 1);
-  constexpr int UF = 4;
-  for (int e0 = beg; !bad && e0 < end; e0 += UF) {
-    int64_t row[UF];
+  constexpr int G = CH > 16 ? CH : 16;
+  constexpr int FP = G / CH;
+  const int bag = vblock * (nthreads / G) + threadIdx.x / G;
+  if (bag >= a.N * a.B) return;
+  const int l = threadIdx.x % G, c = l % CH, q = l / CH;
+  const int s = bag / a.B, b = bag - s * a.B;
+  const int32_t* __restrict__ col = a.slots(s) + b;
+  const float* __restrict__ rec = a.tab.rec;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), sq = sum;
+  float lin = 0.f;
+  bool bad = false;
+  constexpr int UF = 8;
+  for (int f0 = q; f0 < a.T; f0 += FP * UF) {
+    int32_t slot[UF];
     bool ok[UF];
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
-      const bool present = e0 + u < end;
-      const int64_t r = rows[present ? e0 + u : beg];
-      ok[u] = present && r >= 0 && r < local_rows;
-      if (present && !ok[u]) bad = true;
-      row[u] = ok[u] ? r : 0;
-      if (present && c == 0) {
-        rows_out[cbase + e0 + u] = (int32_t) row[u];
-        entry_sample[cbase + e0 + u] = bag;
-      }
+      const int f = f0 + u * FP;
+      slot[u] = f < a.T ? col[(size_t) f * a.B] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      const int f = f0 + u * FP;
+      const int fs = f < a.T ? f : 0;
+      ok[u] = slot[u] >= lo_tab[fs] && slot[u] < lo_tab[fs + 1];
+      if (slot[u] >= 0 && !ok[u]) bad = true;   // a row of another table, or past the shard
     }
     float4 v[UF];
     float w[UF];
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
-      const float* r = tab.rec + row[u] * tab.stride;
-      v[u] = *reinterpret_cast<const float4*>(r + c * 4);
-      w[u] = (c == 0) ? r[tab.off_w1] : 0.f;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      w[u] = 0.f;
+      if (ok[u]) {
+        const float* r = rec + (int64_t) slot[u] * a.tab.stride;
+        v[u] = *reinterpret_cast<const float4*>(r + c * 4);
+        if (c == 0) w[u] = r[a.tab.off_w1];
+      }
     }
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
-      if (ok[u]) {
-        s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
-        q = fmaf(v[u].x, v[u].x, q); q = fmaf(v[u].y, v[u].y, q);
-        q = fmaf(v[u].z, v[u].z, q); q = fmaf(v[u].w, v[u].w, q);
-        lin += w[u];
-      }
+      lin += w[u];
+      sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w;
+      sq.x = fmaf(v[u].x, v[u].x, sq.x); sq.y = fmaf(v[u].y, v[u].y, sq.y);
+      sq.z = fmaf(v[u].z, v[u].z, sq.z); sq.w = fmaf(v[u].w, v[u].w, sq.w);
     }
   }
 #pragma unroll
-  for (int o = 1; o < CH; o <<= 1) q += __shfl_xor(q, o, 64);
-  float* out = partial + (size_t) bag * (DIM + 2);
-  out[c * 4 + 0] = s.x; out[c * 4 + 1] = s.y; out[c * 4 + 2] = s.z; out[c * 4 + 3] = s.w;
-  if (c == 0) { out[DIM] = q; out[DIM + 1] = lin; }
-  if (bad && err) atomicOr(err, MI_IDERR_RANGE);
+  for (int o = CH; o < G; o <<= 1) {  // the field phases of a column chunk
+    sum.x += __shfl_xor(sum.x, o, 64); sum.y += __shfl_xor(sum.y, o, 64);
+    sum.z += __shfl_xor(sum.z, o, 64); sum.w += __shfl_xor(sum.w, o, 64);
+  }
+  float qq = (sq.x + sq.y) + (sq.z + sq.w);
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1) {
+    qq += __shfl_xor(qq, o, 64);
+    lin += __shfl_xor(lin, o, 64);
+  }
+  int anybad = bad ? 1 : 0;
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1) anybad |= __shfl_xor(anybad, o, 64);
+  float* out = a.partial + (size_t) bag * (DIM + 2);
+  if (q == 0) {  // rows of DIM+2 floats are only 8-byte aligned
+    *reinterpret_cast<float2*>(out + c * 4) = make_float2(sum.x, sum.y);
+    *reinterpret_cast<float2*>(out + c * 4 + 2) = make_float2(sum.z, sum.w);
+  }
+  if (l == 0) { out[DIM] = qq; out[DIM + 1] = lin; }
+  if (l == 0 && anybad && a.err) atomicOr(a.err, MI_IDERR_RANGE);
+}
+
+// ---- owner-side sort --------------------------------------------------------------------------
+// Table t's entries at this owner are the valid slots among the N*B of recv[*][t][*]: B on
+// average, N*B at worst, in stream order e = s*B + b - which is also the row of the gathered
+// sample matrix the backward reads, so the sort's payload is simply e.  `parts` workgroups share
+// a table the way the single-GPU sort does (histogram of the top 8 key bits, equal-count cut, no
+// communication).  A range of more than TS_MAX entries is taken apart further: bins are sorted in
+// groups that fit, an over-full bin is refined on its next 8 key bits (at most four levels for a
+// 32-bit key), and an over-full single key needs no sorting at all - its entries are copied in
+// stream order.  So any skew is sorted correctly; only its speed degrades.
+constexpr uint32_t OS_INVALID = 0xFFFFFFFFu;
+constexpr int OS_LEVELS = 4;
+
+struct OwnerStream {
+  const int32_t* slots;  // table t's slots of source 0
+  int64_t stride;        // ints between consecutive sources
+  int B, NC, n_pairs;    // samples per source, 64-slot chunks per source, (source, chunk) pairs = N*NC
+  int64_t lo;
+  uint32_t rows;
+  __device__ __forceinline__ uint32_t to_key(int32_t v) const {
+    const int64_t k = (int64_t) v - lo;
+    return (v >= 0 && k >= 0 && k < (int64_t) rows) ? (uint32_t) k : OS_INVALID;
+  }
+};
+
+// (source, chunk) of pair p, advanced without divisions; wave-uniform (kept in scalar registers)
+struct PairIter {
+  int s, ch;
+  __device__ __forceinline__ PairIter(int p, int NC) : s(p / NC), ch(p - (p / NC) * NC) {}
+  __device__ __forceinline__ void advance(int k, int NC) {
+    ch += k;
+    while (ch >= NC) { ch -= NC; ++s; }
+  }
+};
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); }
+
+// entries of the frame: valid keys with key >> psh == pfx; bin = (key >> sh) & mask
+struct OsFrame {
+  int psh;
+  uint32_t pfx;
+  int sh;
+  uint32_t mask;
+  __device__ __forceinline__ bool in(uint32_t key) const {
+    return key != OS_INVALID && (uint32_t) ((unsigned long long) key >> psh) == pfx;
+  }
+  __device__ __forceinline__ int bin(uint32_t key) const { return (int) ((key >> sh) & mask); }
+};
+
+// Wave w walks its contiguous run of (source, chunk) pairs, OS_FLIGHT chunks in flight (what these
+// passes cost is dependent round trips to memory, so few, wide rounds); f(key, e) is called by all
+// lanes of the wave together for every chunk (key = OS_INVALID past a source's last sample),
+// e = s*B + b being the entry's place in stream order.
+constexpr int OS_FLIGHT = 32;
+template <class F>
+__device__ __forceinline__ void os_stream(const OwnerStream& S, F&& f) {
+  const int lane = threadIdx.x & 63, w = wave_id();
+  const int ppw = (S.n_pairs + TS_WAVES - 1) / TS_WAVES;
+  const int beg = w * ppw, end = min(beg + ppw, S.n_pairs);
+  if (beg >= end) return;
+  PairIter it(beg, S.NC);
+  for (int p0 = beg; p0 < end; p0 += OS_FLIGHT) {
+    int32_t v[OS_FLIGHT];
+    PairIter jt = it;
+#pragma unroll
+    for (int u = 0; u < OS_FLIGHT; ++u) {
+      const int b = jt.ch * 64 + lane;
+      v[u] = (p0 + u < end && b < S.B) ? S.slots[(size_t) jt.s * S.stride + b] : -1;
+      jt.advance(1, S.NC);
+    }
+#pragma unroll
+    for (int u = 0; u < OS_FLIGHT; ++u) {
+      if (p0 + u < end) f(S.to_key(v[u]), it.s * S.B + it.ch * 64 + lane);
+      it.advance(1, S.NC);
+    }
+  }
+}
+
+__device__ __forceinline__ void os_hist(const OwnerStream& S, const OsFrame& fr, uint32_t* hist) {
+  for (int i = threadIdx.x; i < TS_RADIX; i += TS_THREADS) hist[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  os_stream(S, [&](uint32_t key, int) {
+    // integer counts: any order gives the same result.  A skewed table sends most of a wave to one
+    // bin, where 64 atomics on one word would serialise: the lanes that share the first active
+    // lane's bin are counted with a ballot and added once, only the others add for themselves.
+    const bool in = fr.in(key);
+    const int b = in ? fr.bin(key) : -1;
+    const unsigned long long act = __ballot(in);
+    if (act == 0) return;  // uniform over the wave
+    const int lead = __ffsll((long long) act) - 1;
+    const int b0 = __shfl(b, lead, 64);
+    const unsigned long long same = __ballot(b == b0);
+    if (lane == lead) atomicAdd(&hist[b0], (uint32_t) __popcll(same));
+    if (in && b != b0) atomicAdd(&hist[b], 1u);
+  });
+  __syncthreads();
+}
+
+// Stable selection of the frame's entries with bin in [b0, b1): into LDS image 0 (to_lds) or, for
+// a single over-full key, straight to the output at sorted_rows/perm + out.  Returns nothing; the
+// count is known from the histogram.
+__device__ __forceinline__ void os_select(TsLds& L, const OwnerStream& S, const OsFrame& fr, int b0, int b1,
+                                          bool to_lds, uint32_t* __restrict__ sorted_rows,
+                                          uint32_t* __restrict__ perm, size_t out) {
+  const int lane = threadIdx.x & 63, w = wave_id();
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int mine = 0;
+  os_stream(S, [&](uint32_t key, int) {
+    const int b = fr.bin(key);
+    mine += __popcll(__ballot(fr.in(key) && b >= b0 && b < b1));
+  });
+  __syncthreads();  // L.wsum may still be read by the previous user
+  if (lane == 0) L.wsum[w] = (uint32_t) mine;
+  __syncthreads();
+  uint32_t at = 0;
+  for (int i = 0; i < w; ++i) at += L.wsum[i];
+  os_stream(S, [&](uint32_t key, int e) {
+    const int b = fr.bin(key);
+    const bool sel = fr.in(key) && b >= b0 && b < b1;
+    const unsigned long long bal = __ballot(sel);
+    if (sel) {
+      const uint32_t d = at + (uint32_t) __popcll(bal & lt);
+      if (to_lds) {
+        L.kbuf[0][d] = key;
+        L.vbuf[0][d] = (uint32_t) e;
+      } else {
+        sorted_rows[out + d] = (uint32_t) (S.lo + key);
+        perm[out + d] = (uint32_t) e;
+      }
+    }
+    at += (uint32_t) __popcll(bal);
+  });
+  __syncthreads();
+}
+
+// Emits, in key order, the frame's entries whose bin lies in [i, end), to the output position
+// `out` (advanced).  hist = L-resident bin counts of this frame.
+template <int LEVEL>
+__device__ __forceinline__ void os_emit(TsLds& L, uint32_t (*lvl)[TS_RADIX], const OwnerStream& S, const OsFrame& fr,
+                                        int i, int end, int bits, uint32_t* __restrict__ sorted_rows,
+                                        uint32_t* __restrict__ perm, size_t& out) {
+  const uint32_t* hist = lvl[LEVEL];
+  while (i < end) {  // uniform over the workgroup
+    const uint32_t c = hist[i];
+    if (c == 0) { ++i; continue; }
+    if (c > (uint32_t) TS_MAX) {
+      if (fr.sh == 0) {  // one key: no order to establish
+        os_select(L, S, fr, i, i + 1, false, sorted_rows, perm, out);
+        out += c;
+      } else if constexpr (LEVEL + 1 < OS_LEVELS) {
+        OsFrame ch;
+        ch.psh = fr.sh;
+        ch.pfx = (uint32_t) ((((unsigned long long) fr.pfx << (fr.psh - fr.sh)) & 0xFFFFFFFFull) | (uint32_t) i);
+        ch.sh = fr.sh > 8 ? fr.sh - 8 : 0;
+        ch.mask = (1u << (fr.sh - ch.sh)) - 1u;
+        os_hist(S, ch, lvl[LEVEL + 1]);
+        os_emit<LEVEL + 1>(L, lvl, S, ch, 0, (int) ch.mask + 1, bits, sorted_rows, perm, out);
+      }
+      ++i;
+      continue;
+    }
+    int j = i;
+    uint32_t m = 0;
+    while (j < end && m + hist[j] <= (uint32_t) TS_MAX) m += hist[j++];
+    os_select(L, S, fr, i, j, true, nullptr, nullptr, 0);
+    const int nbits = min(bits, fr.sh + 8);
+    const int cur = ts_lds_sort(L, (int) m, (nbits + 7) / 8, 0);
+    for (int e = threadIdx.x; e < (int) m; e += TS_THREADS) {
+      sorted_rows[out + e] = (uint32_t) (S.lo + L.kbuf[cur][e]);
+      perm[out + e] = L.vbuf[cur][e];
+    }
+    __syncthreads();  // the images are free again
+    out += m;
+    i = j;
+  }
+}
+
+// The n <= 2*TS_MAX valid (key, value) pairs of a table lie in the two key images / two value images
+// of L taken as one array each.  Cuts the key range as ts_sort_part does; when this part's share
+// fits one image (m <= TS_MAX) it is compacted in place to the front (stable), sorted, and the
+// image holding it is returned.  A larger share that is one key is written straight to
+// sorted_rows / perm [base + ..) (returns -2); any other larger share returns -1, nothing moved.
+// All threads call this.
+constexpr int OS_FLAT = 2 * TS_MAX;
+constexpr int OS_ITEMS = OS_FLAT / TS_THREADS;  // 16
+__device__ __forceinline__ int os_sort_flat(TsLds& L, int n, int part, int parts, int bits, int& m_out,
+                                            int& out_base_out, uint32_t lo, uint32_t* __restrict__ sorted_rows,
+                                            uint32_t* __restrict__ perm, size_t base) {
+  uint32_t* fk = &L.kbuf[0][0];
+  uint32_t* fv = &L.vbuf[0][0];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int top = bits > 8 ? bits - 8 : 0;
+  if (tid < TS_RADIX) L.dbase[tid] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < OS_ITEMS; ++k) {
+    const int e = k * TS_THREADS + tid;
+    if (e < n) atomicAdd(&L.dbase[fk[e] >> top], 1u);  // integer counts: any order gives the same result
+  }
+  __syncthreads();
+  uint32_t c = tid < TS_RADIX ? L.dbase[tid] : 0u, inc = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t x = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += x;
+  }
+  if (tid < TS_RADIX && lane == 63) L.wsum[w] = inc;
+  __syncthreads();
+  if (tid < TS_RADIX) {
+    uint32_t wb = 0;
+    for (int i = 0; i < w; ++i) wb += L.wsum[i];
+    L.qsum[0][tid] = wb + inc - c;
+  }
+  __syncthreads();
+  if (tid < TS_RADIX) {
+    const uint32_t mine = L.qsum[0][tid], next = tid + 1 < TS_RADIX ? L.qsum[0][tid + 1] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int q = part + s;
+      if (q > 0 && q < parts) {
+        const uint32_t target = (uint32_t) (((int64_t) q * n) / parts);
+        if (mine <= target && next > target) L.cut[s] = tid;
+      }
+    }
+  }
+  if (tid == 0) {
+    if (part == 0) L.cut[0] = 0;
+    if (part == parts - 1) L.cut[1] = TS_RADIX;
+  }
+  __syncthreads();
+  const int b_lo = L.cut[0], b_hi = L.cut[1];
+  const int out_base = (int) L.qsum[0][b_lo];
+  const int m = (b_hi == TS_RADIX ? n : (int) L.qsum[0][b_hi]) - out_base;
+  m_out = m;
+  out_base_out = out_base;
+  // a share that does not fit one image: hopeless here unless it is a single key (then its entries
+  // only have to be copied out in order)
+  const bool direct = m > TS_MAX && top == 0 && b_hi == b_lo + 1;
+  if (m > TS_MAX && !direct) return -1;
+  // stable selection, in place: everything is read into registers before anything is written
+  unsigned long long bal[OS_ITEMS];
+  uint32_t key[OS_ITEMS], val[OS_ITEMS];
+  const int wbase = w * (MI_WAVE * OS_ITEMS);
+#pragma unroll
+  for (int j = 0; j < OS_ITEMS; ++j) {
+    const int e = wbase + j * MI_WAVE + lane;
+    key[j] = e < n ? fk[e] : 0u;
+    val[j] = e < n ? fv[e] : 0u;
+    const int bin = (int) (key[j] >> top);
+    bal[j] = __ballot(e < n && bin >= b_lo && bin < b_hi);
+    if (lane == 0) L.qsum[1][w * OS_ITEMS + j] = (uint32_t) __popcll(bal[j]);
+  }
+  __syncthreads();
+  if (tid < TS_WAVES * OS_ITEMS) {  // 256 group counts -> exclusive prefix (four waves)
+    const uint32_t g = L.qsum[1][tid];
+    uint32_t gi = g;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t x = __shfl_up(gi, o, 64);
+      if (lane >= o) gi += x;
+    }
+    if (lane == 63) L.wsum[w] = gi;
+    L.qsum[2][tid] = gi - g;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < OS_ITEMS; ++j) {
+    if ((bal[j] >> lane) & 1ull) {
+      const int g = w * OS_ITEMS + j;
+      uint32_t before = 0;
+      for (int i = 0; i < (g >> 6); ++i) before += L.wsum[i];
+      const uint32_t dest = L.qsum[2][g] + before + (uint32_t) __popcll(bal[j] & lt);
+      if (direct) {
+        sorted_rows[base + out_base + dest] = lo + key[j];
+        perm[base + out_base + dest] = val[j];
+      } else {
+        fk[dest] = key[j];
+        fv[dest] = val[j];
+      }
+    }
+  }
+  if (direct) return -2;
+  __syncthreads();
+  const int passes = (bits + 7) / 8;
+  const int cur = ts_lds_sort(L, m, passes, 0);
+  if (passes == 0) __syncthreads();
+  return cur;
+}
+
+// Part `part` of `parts` of table t.  The output is compact: table t's entries follow those of the
+// tables before it (their numbers come from the chunk counts the requesters sent along), and
+// n_total[0] = the number of entries of all tables.
+//
+// Usual case, at most 2*TS_MAX entries for the table (the average is B) and a share of at most
+// TS_MAX for this part: the chunk counts give every 64-slot chunk its place, so ONE pass over the
+// slots compacts the valid ones into LDS in stream order, and the rest is the single-GPU per-table
+// sort.  Otherwise the streaming multi-level path above (same cut, so the parts of a table may
+// take different paths).
+__device__ __forceinline__ void owner_sort_body(TsLds& L, uint32_t (*lvl)[TS_RADIX], const OwnerArgs& a, int t, int part,
+                                                int parts, uint32_t* __restrict__ sorted_rows,
+                                                uint32_t* __restrict__ perm, int32_t* __restrict__ n_total) {
+  const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int T = a.T, N = a.N, NC = a.n_chunks;
+  OwnerStream S;
+  S.slots = a.slots(0) + (size_t) t * a.B;
+  S.stride = a.stride;
+  S.B = a.B; S.NC = NC; S.n_pairs = N * NC;
+  S.lo = first_local(a.toffs, t, a.rank, N);
+  S.rows = (uint32_t) (first_local(a.toffs, t + 1, a.rank, N) - S.lo);
+  int bits = 0;
+  for (uint32_t v = S.rows; v; v >>= 1) ++bits;
+  // entries per table from the chunk counts: thread (g, t') sums cnt[s][c][t'] over the (s, c) pairs
+  // g, g+G, ...; then the G partials of a table are added in order
+  uint32_t* tsum = &lvl[0][0];  // [T <= 64] totals, then [T+1] exclusive prefix behind them
+  const bool vec = (a.B % 256 == 0) && (((uintptr_t) a.recv & 15) == 0);  // then every block, count row and slot row is 16-byte aligned
+  if (vec) {
+    // integer sums: LDS atomics, any order gives the same totals
+    if (tid < 64) tsum[tid] = 0;
+    __syncthreads();
+    const int per_src = NC * T / 4;  // int4 per source (NC % 4 == 0)
+    for (int s = 0; s < N; ++s) {
+      const int4* c4 = reinterpret_cast<const int4*>(a.cnt(s));
+      for (int i = tid; i < per_src; i += TS_THREADS) {
+        const int4 v = c4[i];
+        int tp = (4 * i) % T;
+        atomicAdd(&tsum[tp], (uint32_t) v.x); tp = tp + 1 == T ? 0 : tp + 1;
+        atomicAdd(&tsum[tp], (uint32_t) v.y); tp = tp + 1 == T ? 0 : tp + 1;
+        atomicAdd(&tsum[tp], (uint32_t) v.z); tp = tp + 1 == T ? 0 : tp + 1;
+        atomicAdd(&tsum[tp], (uint32_t) v.w);
+      }
+    }
+    __syncthreads();
+  } else {
+    const int tp = lane, g = w;  // G = TS_WAVES groups
+    uint32_t acc = 0;
+    PairIter it(g, NC);
+    for (int sc0 = g; sc0 < N * NC; sc0 += TS_WAVES * 8) {
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[u] = (sc0 + u * TS_WAVES < N * NC && tp < T) ? (uint32_t) a.cnt(it.s)[it.ch * T + tp] : 0u;
+        it.advance(TS_WAVES, NC);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    L.cnt[g][tp] = acc;
+    __syncthreads();
+    if (tid < T) {
+      uint32_t tot = 0;
+      for (int i = 0; i < TS_WAVES; ++i) tot += L.cnt[i][tid];
+      tsum[tid] = tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < T; ++i) { tsum[64 + i] = run; run += tsum[i]; }
+    tsum[64 + T] = run;
+  }
+  __syncthreads();
+  const uint32_t n_valid = tsum[t];
+  const size_t base = tsum[64 + t];
+  if (t == 0 && part == 0 && tid == 0) n_total[0] = (int32_t) tsum[64 + T];
+  __syncthreads();  // lvl[0] is reused below
+  // Units of the slot pass: 64-slot chunks, or groups of four chunks read as one int4 per lane when
+  // everything is 16-byte aligned (B % 256 == 0).  Unit u = (source, unit of that source).
+  const int UPS = vec ? NC / 4 : NC;  // units per source
+  const int n_units = N * UPS;
+  const bool one_key = S.rows == 1;   // a single local row: nothing to sort, any number of entries
+  if (n_units <= TS_WAVES * TS_RADIX &&
+      (one_key || (n_valid <= (uint32_t) OS_FLAT && (parts > 1 || n_valid <= (uint32_t) TS_MAX)))) {
+    uint32_t* fk = &L.kbuf[0][0];
+    uint32_t* fv = &L.vbuf[0][0];
+    // place of every unit: exclusive prefix of this table's chunk counts, kept in L.cnt
+    uint32_t* cbase = &L.cnt[0][0];
+    uint32_t carry = 0;
+    for (int p0 = 0; p0 < n_units; p0 += TS_THREADS) {  // uniform
+      const int p = p0 + tid;
+      uint32_t c = 0;
+      if (p < n_units) {
+        const int s = p / UPS, j = p - s * UPS;
+        const int32_t* cs = a.cnt(s);
+        if (vec) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) c += (uint32_t) cs[(4 * j + i) * T + t];
+        } else {
+          c = (uint32_t) cs[j * T + t];
+        }
+      }
+      uint32_t inc = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t x = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += x;
+      }
+      if (lane == 63) L.wsum[w] = inc;
+      __syncthreads();
+      uint32_t wb = 0, all = 0;
+      for (int i = 0; i < TS_WAVES; ++i) {
+        if (i < w) wb += L.wsum[i];
+        all += L.wsum[i];
+      }
+      if (p < n_units) cbase[p] = carry + wb + inc - c;
+      carry += all;
+      __syncthreads();
+    }
+    // One pass over the slots.  one_key: the parts share the units and write the entries straight to
+    // their places; otherwise every part stages all of the table's entries in LDS (wave w takes
+    // units w, w+16, ...).
+    const int u_lo = one_key ? (int) ((int64_t) n_units * part / parts) : 0;
+    const int u_hi = one_key ? (int) ((int64_t) n_units * (part + 1) / parts) : n_units;
+    auto put = [&](uint32_t d, uint32_t key, uint32_t e) {
+      if (one_key) {
+        sorted_rows[base + d] = (uint32_t) S.lo;
+        perm[base + d] = e;
+      } else if (d < (uint32_t) OS_FLAT) {  // counts and slots disagree only if the exchange was corrupted
+        fk[d] = key;
+        fv[d] = e;
+      }
+    };
+    const uint32_t kmax = S.rows ? S.rows - 1 : 0;  // a slot of another table (reported by the forward) must not leave the key range
+    if (vec) {
+      constexpr int FL = 8;
+      PairIter it(u_lo + w, UPS);
+      for (int p0 = u_lo + w; p0 < u_hi; p0 += TS_WAVES * FL) {
+        int4 v[FL];
+        PairIter jt = it;
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+          v[u] = make_int4(-1, -1, -1, -1);
+          if (p0 + u * TS_WAVES < u_hi)
+            v[u] = *reinterpret_cast<const int4*>(S.slots + (size_t) jt.s * S.stride + jt.ch * 256 + lane * 4);
+          jt.advance(TS_WAVES, UPS);
+        }
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+          const int p = p0 + u * TS_WAVES;
+          if (p < u_hi) {  // uniform over the wave
+            const int32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            const unsigned long long any = __ballot((x[0] & x[1] & x[2] & x[3]) >= 0);
+            if (any) {
+              uint32_t before = 0;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) before += (uint32_t) __popcll(__ballot(x[k] >= 0) & lt);
+              uint32_t d = cbase[p] + before;
+              const uint32_t e0 = (uint32_t) (it.s * a.B + it.ch * 256 + lane * 4);
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (x[k] >= 0) put(d++, min((uint32_t) ((int64_t) x[k] - S.lo), kmax), e0 + k);
+            }
+          }
+          it.advance(TS_WAVES, UPS);
+        }
+      }
+    } else {
+      constexpr int FL = 8;
+      PairIter it(u_lo + w, UPS);
+      for (int p0 = u_lo + w; p0 < u_hi; p0 += TS_WAVES * FL) {
+        int32_t v[FL];
+        PairIter jt = it;
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+          const int b = jt.ch * 64 + lane;
+          v[u] = (p0 + u * TS_WAVES < u_hi && b < a.B) ? S.slots[(size_t) jt.s * S.stride + b] : -1;
+          jt.advance(TS_WAVES, UPS);
+        }
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+          const int p = p0 + u * TS_WAVES;
+          if (p < u_hi) {  // uniform over the wave
+            const bool ok = v[u] >= 0;
+            const unsigned long long bal = __ballot(ok);
+            if (ok)
+              put(cbase[p] + (uint32_t) __popcll(bal & lt), min((uint32_t) ((int64_t) v[u] - S.lo), kmax),
+                  (uint32_t) (it.s * a.B + it.ch * 64 + lane));
+          }
+          it.advance(TS_WAVES, UPS);
+        }
+      }
+    }
+    if (one_key) return;
+    __syncthreads();
+    int m, out_base, cur;
+    if (parts > 1) {
+      cur = os_sort_flat(L, (int) n_valid, part, parts, bits, m, out_base, (uint32_t) S.lo, sorted_rows, perm, base);
+    } else {
+      m = (int) n_valid;
+      out_base = 0;
+      cur = ts_lds_sort(L, m, (bits + 7) / 8, 0);
+      if (bits == 0) __syncthreads();
+    }
+    if (cur == -2) return;  // written by os_sort_flat
+    if (cur >= 0) {
+      const size_t out = base + out_base;
+      for (int e = tid; e < m; e += TS_THREADS) {
+        sorted_rows[out + e] = (uint32_t) (S.lo + L.kbuf[cur][e]);
+        perm[out + e] = L.vbuf[cur][e];
+      }
+      return;
+    }
+    __syncthreads();  // this part's share does not fit: stream it
+  }
+  // streaming path
+  OsFrame top;
+  top.psh = 32; top.pfx = 0;
+  top.sh = bits > 8 ? bits - 8 : 0;
+  top.mask = TS_RADIX - 1;
+  os_hist(S, top, lvl[0]);
+  uint32_t c = tid < TS_RADIX ? lvl[0][tid] : 0u, inc = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t x = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += x;
+  }
+  if (tid < TS_RADIX && lane == 63) L.wsum[w] = inc;
+  __syncthreads();
+  const uint32_t n_seen = L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
+  if (tid < TS_RADIX) {
+    uint32_t wb = 0;
+    for (int i = 0; i < w; ++i) wb += L.wsum[i];
+    L.dbase[tid] = wb + inc - c;
+  }
+  __syncthreads();
+  if (tid < TS_RADIX) {
+    const uint32_t mine = L.dbase[tid], next = tid + 1 < TS_RADIX ? L.dbase[tid + 1] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int q = part + s;
+      if (q > 0 && q < parts) {
+        const uint32_t target = (uint32_t) (((int64_t) q * n_seen) / parts);
+        if (mine <= target && next > target) L.cut[s] = tid;
+      }
+    }
+  }
+  if (tid == 0) {
+    if (part == 0) L.cut[0] = 0;
+    if (part == parts - 1) L.cut[1] = TS_RADIX;
+  }
+  __syncthreads();
+  const int b_lo = L.cut[0], b_hi = L.cut[1];
+  size_t out = base + L.dbase[b_lo];
+  __syncthreads();  // L.dbase and L.wsum are reused by the sort
+  os_emit<0>(L, lvl, S, top, b_lo, b_hi, bits, sorted_rows, perm, out);
+}
+
+// One launch for everything an owner can do once the slots have arrived: workgroups [0, T*parts)
+// sort, the others run the partial forward, one thread advances the optimizer schedule.
+template <int DIM>
+__global__ __launch_bounds__(TS_THREADS) void owner_fwd_sort_kernel(OwnerArgs a, int parts,
+                                                                   uint32_t* __restrict__ sorted_rows,
+                                                                   uint32_t* __restrict__ perm,
+                                                                   int32_t* __restrict__ n_total,
+                                                                   float* __restrict__ sched, float lr, float b1,
+                                                                   float b2) {
+  const int sort_blocks = sorted_rows ? a.T * parts : 0;
+  if ((int) blockIdx.x < sort_blocks) {
+    __shared__ TsLds L;
+    __shared__ uint32_t lvl[OS_LEVELS][TS_RADIX];
+    owner_sort_body(L, lvl, a, blockIdx.x / parts, blockIdx.x % parts, parts, sorted_rows, perm, n_total);
+    return;
+  }
+  extern __shared__ int32_t lo_tab[];  // first local row of every table, T+1 entries
+  for (int t = threadIdx.x; t <= a.T; t += TS_THREADS) lo_tab[t] = (int32_t) first_local(a.toffs, t, a.rank, a.N);
+  __syncthreads();
+  if (sched && (int) blockIdx.x == sort_blocks && threadIdx.x == 0) adam_schedule_body(sched, lr, b1, b2);
+  owner_fwd_body<DIM>(a, blockIdx.x - sort_blocks, TS_THREADS, lo_tab);
 }
 
 // Requester side: sum the owners' partials in rank order, add the dense part and the bias, and
@@ -231,58 +786,64 @@ __global__ __launch_bounds__(256) void fm_combine_kernel(const float* __restrict
 
 }  // namespace
 
-extern "C" int64_t mi_shard_block_ints(int64_t B, int T) { return B + 1 + B * T; }
+extern "C" int64_t mi_shard_block_ints(int64_t B, int T) { return mi_cdiv(B, ROUTE_SAMPLES) * T + B * T; }
 
 extern "C" int mi_shard_route(const int64_t* table_offsets, int T, const void* ids, int idx_bits, int64_t B,
                               int n_ranks, int32_t* send, int32_t* err, void* stream) {
   MI_REQUIRE(table_offsets && ids && send, "mi_shard_route: null pointer");
-  MI_REQUIRE(T >= 1 && B >= 1 && B < ((int64_t) 1 << 31) / T / 17, "mi_shard_route: bad T/B");
+  MI_REQUIRE(T >= 1 && T <= 64 && B >= 1 && B < ((int64_t) 1 << 31) / T / 17, "mi_shard_route: bad T/B (T <= 64)");
   MI_REQUIRE(n_ranks >= 1 && n_ranks <= MAX_RANKS, "mi_shard_route: n_ranks must be 1..%d", MAX_RANKS);
   MI_REQUIRE(idx_bits == 32 || idx_bits == 64, "mi_shard_route: idx_bits must be 32 or 64");
   hipStream_t s = (hipStream_t) stream;
-  const unsigned grid = (unsigned) mi_cdiv(B, 256);
-  const int stride = (int) mi_shard_block_ints(B, T);
+  const unsigned grid = (unsigned) mi_cdiv(B, ROUTE_SAMPLES);
+  const size_t lds = (size_t) 2 * T * ROUTE_SAMPLES * sizeof(int32_t);
   if (idx_bits == 32)
-    hipLaunchKernelGGL(route_count_kernel<int32_t>, dim3(grid), dim3(256), 0, s, table_offsets, T, ids, (int) B,
-                       n_ranks, stride, send, err);
+    hipLaunchKernelGGL(route_kernel<int32_t>, dim3(grid), dim3(ROUTE_THREADS), lds, s, table_offsets, T, ids, (int) B, n_ranks,
+                       mi_shard_block_ints(B, T), send, err);
   else
-    hipLaunchKernelGGL(route_count_kernel<int64_t>, dim3(grid), dim3(256), 0, s, table_offsets, T, ids, (int) B,
-                       n_ranks, stride, send, err);
-  hipLaunchKernelGGL(route_scan_kernel, dim3(n_ranks), dim3(256), 0, s, send, (int) B, stride);
-  if (idx_bits == 32)
-    hipLaunchKernelGGL(route_fill_kernel<int32_t>, dim3(grid), dim3(256), 0, s, table_offsets, T, ids, (int) B,
-                       n_ranks, stride, send);
-  else
-    hipLaunchKernelGGL(route_fill_kernel<int64_t>, dim3(grid), dim3(256), 0, s, table_offsets, T, ids, (int) B,
-                       n_ranks, stride, send);
+    hipLaunchKernelGGL(route_kernel<int64_t>, dim3(grid), dim3(ROUTE_THREADS), lds, s, table_offsets, T, ids, (int) B, n_ranks,
+                       mi_shard_block_ints(B, T), send, err);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
 
-extern "C" int mi_fm_partial_fwd(const mi_fm_table* tab, int64_t local_rows, const int32_t* recv, int n_ranks,
-                                 int64_t B, int T, float* partial, int32_t* rows_out, int32_t* entry_sample,
-                                 int32_t* n_out, int32_t* err, void* stream) {
-  const int rc = mi_fm_check_table(tab, MI_OPT_SGD, "mi_fm_partial_fwd");
+extern "C" int mi_shard_owner_fwd_sort(const mi_fm_table* tab, int64_t local_rows, const int64_t* table_offsets, int T,
+                                       int rank, int n_ranks, const int32_t* recv, int64_t B, float* partial,
+                                       uint32_t* sorted_rows, int32_t* perm, int32_t* n_total, float* sched,
+                                       float lr, float beta1, float beta2, int32_t* err, void* stream) {
+  const char* who = "mi_shard_owner_fwd_sort";
+  const int rc = mi_fm_check_table(tab, MI_OPT_SGD, who);
   if (rc) return rc;
-  MI_REQUIRE(recv && partial && rows_out && entry_sample && n_out, "mi_fm_partial_fwd: null pointer");
-  MI_REQUIRE(n_ranks >= 1 && n_ranks <= MAX_RANKS && T >= 1 && B >= 1 && B < ((int64_t) 1 << 31) / T / 17,
-             "mi_fm_partial_fwd: bad n_ranks/B/T");
+  MI_REQUIRE(table_offsets && recv && partial, "%s: null pointer", who);
+  MI_REQUIRE((sorted_rows == nullptr) == (perm == nullptr) && (sorted_rows == nullptr) == (n_total == nullptr),
+             "%s: sorted_rows, perm and n_total go together", who);
+  MI_REQUIRE(T <= 64, "%s: at most 64 tables", who);
+  MI_REQUIRE(local_rows >= 1 && local_rows < (int64_t) 0x7FFFFFFFll, "%s: local_rows must fit an int32 slot", who);
+  MI_REQUIRE(n_ranks >= 1 && n_ranks <= MAX_RANKS && rank >= 0 && rank < n_ranks && T >= 1 && B >= 1 &&
+                 B < ((int64_t) 1 << 24) / n_ranks && (int64_t) n_ranks * B * T < ((int64_t) 1 << 31),
+             "%s: bad rank/n_ranks/B/T (n_ranks*B < 2^24)", who);
+  OwnerArgs a{*tab, table_offsets, recv, mi_shard_block_ints(B, T), T, (int) B, n_ranks, rank,
+              (int) mi_cdiv(B, ROUTE_SAMPLES), partial, err};
   hipStream_t s = (hipStream_t) stream;
   const int64_t bags = (int64_t) n_ranks * B;
-  const int stride = (int) mi_shard_block_ints(B, T);
-#define PF_CASE(D)                                                                                               \
-  case D:                                                                                                        \
-    hipLaunchKernelGGL(fm_partial_fwd_kernel<D>, dim3((unsigned) mi_cdiv(bags, 256 / (D / 4))), dim3(256), 0, s, \
-                       *tab, recv, stride, n_ranks, (int) B, local_rows, partial, rows_out, entry_sample, n_out, \
-                       err);                                                                                     \
-    break;
+  const size_t lds = (size_t) (T + 1) * sizeof(int32_t);
+#define OW_CASE(D)                                                                                                  \
+  case D: {                                                                                                         \
+    constexpr int G_ = (D / 4) > 16 ? (D / 4) : 16;                                                                 \
+    const int fwd_blocks_ = (int) mi_cdiv(bags, TS_THREADS / G_);                                                   \
+    const int parts_ = sorted_rows ? mi_table_sort_parts(T, (int) B, 0) : 0;                                        \
+    hipLaunchKernelGGL((owner_fwd_sort_kernel<D>), dim3((unsigned) (T * parts_ + fwd_blocks_)), dim3(TS_THREADS),   \
+                       lds, s, a, parts_, sorted_rows, reinterpret_cast<uint32_t*>(perm), n_total, sched, lr, beta1, \
+                       beta2);                                                                                      \
+    break;                                                                                                          \
+  }
   switch (tab->dim) {
-    PF_CASE(4) PF_CASE(8) PF_CASE(16) PF_CASE(32) PF_CASE(64) PF_CASE(128)
+    OW_CASE(4) OW_CASE(8) OW_CASE(16) OW_CASE(32) OW_CASE(64) OW_CASE(128)
     default:
-      mi_set_error("mi_fm_partial_fwd: dim %d not built (4, 8, 16, 32, 64, 128)", tab->dim);
+      mi_set_error("%s: dim %d not built (4, 8, 16, 32, 64, 128)", who, tab->dim);
       return MI_ERR_UNSUPPORTED;
   }
-#undef PF_CASE
+#undef OW_CASE
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

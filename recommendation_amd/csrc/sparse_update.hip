@@ -36,6 +36,7 @@ struct PlanDev {
   const int32_t* seg_offsets;
   const int32_t* counts;
   int32_t* long_list;  // [0] count, [1] finished-workgroup ticket, [2..] queued runs
+  const int32_t* n_dev;  // when set, the number of entries is read from the device (n is then its upper bound)
   const int64_t* offsets;
   const void* indices;
   const int64_t* toffs;
@@ -538,11 +539,17 @@ struct FmDenseExtra {
   FmDenseArgs a;
   __device__ __forceinline__ void run(int j, float* sh) const { fm_dense_body(a, j, sh); }
 };
+struct FmDenseRowsExtra {
+  int blocks;
+  FmDenseRowsArgs a;
+  __device__ __forceinline__ void run(int j, float* sh) const { fm_dense_rows_body(a, j, sh); }
+};
 static_assert(FM_DENSE_THREADS == UBLOCK, "the dense side runs in workgroups of the sparse update's size");
 
 template <int VEC, class Src, class Upd, class Extra>
 __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src, Upd upd, int lanes, int groups,
                                                            int long_blocks, Extra extra) {
+  if (pl.n_dev) pl.n = min(pl.n, pl.n_dev[0]);
   const uint32_t* keys = pl.sorted_rows;
   const uint32_t sentinel = pl.sentinel;
   if ((int) blockIdx.x < extra.blocks) {
@@ -710,6 +717,7 @@ int check_plan(const mi_bwd_plan* plan, PlanDev* pl, bool need_runs, const char*
   pl->seg_offsets = plan->seg_offsets;
   pl->counts = plan->counts;
   pl->long_list = plan->long_list;
+  pl->n_dev = nullptr;
   pl->offsets = plan->offsets;
   pl->indices = plan->indices;
   pl->toffs = plan->table_offsets;
@@ -857,10 +865,11 @@ template <class Extra>
 static int fm_bwd_apply_impl(const char* who, const mi_bwd_plan* plan, const mi_fm_table* tab, const float* g,
                              int g_ld, const float* S, int S_ld, const int32_t* entry_sample, int opt, float lr,
                              const float* lr_dev, float beta1, float beta2, float eps, void* stream,
-                             const Extra& extra) {
+                             const Extra& extra, const int32_t* n_dev = nullptr) {
   PlanDev pl;
   int rc = check_plan(plan, &pl, false, who);
   if (rc) return rc;
+  pl.n_dev = n_dev;
   MI_REQUIRE(g && S, "%s: null pointer", who);
   rc = mi_fm_check_table(tab, opt, who);
   if (rc) return rc;
@@ -905,12 +914,49 @@ extern "C" int mi_fm_bwd_apply(const mi_bwd_plan* plan, const mi_fm_table* tab, 
                            beta2, eps, stream, NoExtra{0});
 }
 
-extern "C" int mi_fm_bwd_apply_rows(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* X, int ld,
-                                    const int32_t* entry_sample, int opt, float lr, const float* lr_dev, float beta1,
-                                    float beta2, float eps, void* stream) {
-  MI_REQUIRE(tab && X && entry_sample, "mi_fm_bwd_apply_rows: null pointer");
-  return fm_bwd_apply_impl("mi_fm_bwd_apply_rows", plan, tab, X + tab->dim, ld, X, ld, entry_sample, opt, lr, lr_dev,
-                           beta1, beta2, eps, stream, NoExtra{0});
+extern "C" int64_t mi_shard_dense_scratch_floats(int64_t rows, int n_dense) {
+  int ct = 1;
+  while (ct < n_dense + 2) ct <<= 1;
+  const int64_t chunks = rows < 1 ? 1 : (rows + 255) / 256 > 512 ? 512 : (rows + 255) / 256;
+  return chunks * ct + 1;  // partials + the ticket word
+}
+
+extern "C" int mi_shard_owner_bwd_dense(const mi_fm_table* tab, int64_t local_rows, const uint32_t* sorted_rows,
+                                        const int32_t* perm, const int32_t* n_total, int64_t n_slots, const float* X,
+                                        int ld, int64_t rows,
+                                        int opt, float lr, const float* lr_dev, float beta1, float beta2, float eps,
+                                        int n_dense, float* dp, float* dm, float* dv, float dense_lr_t,
+                                        const float* dense_lr_dev, float* scratch, float* loss_out, void* stream) {
+  const char* who = "mi_shard_owner_bwd_dense";
+  MI_REQUIRE(tab && sorted_rows && perm && n_total && X && dp && dm && dv && scratch && loss_out, "%s: null pointer",
+             who);
+  MI_REQUIRE(n_slots >= 0 && n_slots < ((int64_t) 1 << 31) && rows >= 1 && n_dense >= 0 &&
+                 n_dense + 2 <= FM_DENSE_THREADS && ld >= tab->dim + 2 + n_dense,
+             "%s: bad n_slots/rows/n_dense/ld", who);
+  MI_REQUIRE(local_rows >= 1 && local_rows < (int64_t) 0x7FFFFFFFll, "%s: local_rows out of range", who);
+  mi_bwd_plan plan = {};
+  plan.sorted_rows = sorted_rows;
+  plan.perm = perm;
+  plan.long_list = reinterpret_cast<int32_t*>(scratch);  // required non-NULL; a plan without run arrays never uses it
+  plan.T = 1;  // entry p's sample is p itself: the sort's payload is the row of X
+  plan.n_entries = n_slots;
+  plan.n_bags = n_slots;
+  plan.bag_len = 1;
+  plan.total_rows = local_rows;
+  plan.pool_mode = MI_POOL_SUM;
+  FmDenseRowsExtra extra;
+  FmDenseRowsArgs& a = extra.a;
+  a.ct = 1;
+  while (a.ct < n_dense + 2) a.ct <<= 1;
+  a.chunks = (int) (mi_shard_dense_scratch_floats(rows, n_dense) - 1) / a.ct;
+  extra.blocks = a.chunks;
+  a.X = X; a.ld = ld; a.rows = rows; a.dim = tab->dim; a.n_dense = n_dense;
+  a.part = scratch;
+  a.ticket = reinterpret_cast<int*>(scratch + (size_t) a.chunks * a.ct);
+  a.dp = dp; a.dm = dm; a.dv = dv; a.lr_t = dense_lr_t; a.lr_dev = dense_lr_dev;
+  a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.loss_out = loss_out;
+  return fm_bwd_apply_impl(who, &plan, tab, X + tab->dim, ld, X, ld, nullptr, opt, lr, lr_dev, beta1, beta2, eps,
+                           stream, extra, n_total);
 }
 
 extern "C" int mi_fm_bwd_apply_dense(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* g, const float* S,

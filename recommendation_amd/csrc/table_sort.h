@@ -34,128 +34,33 @@ static inline int mi_table_sort_parts(int T, int per_table, int other_blocks) {
   return parts;
 }
 
-// Part `part` of `parts` of table `t` is sorted by the calling workgroup (all TS_THREADS threads
-// take part).
-template <typename IDX>
-__device__ __forceinline__ void table_sort_body(int t, int part, int parts, const int64_t* __restrict__ toffs, int T,
-                                                const void* __restrict__ indices, int bag_len, int n,
-                                                uint32_t sentinel, uint32_t* __restrict__ sorted_rows,
-                                                uint32_t* __restrict__ perm) {
-  __shared__ uint32_t kbuf[2][TS_MAX];
-  __shared__ uint32_t vbuf[2][TS_MAX];
-  __shared__ uint32_t cnt[TS_WAVES][TS_RADIX];
-  __shared__ uint32_t dbase[TS_RADIX];
-  __shared__ uint32_t qsum[4][TS_RADIX];
-  __shared__ uint32_t wsum[4];
-  __shared__ int cut[2];
+// The LDS arrays of a sorting workgroup (152 KB: one workgroup per CU).
+struct TsLds {
+  uint32_t kbuf[2][TS_MAX];
+  uint32_t vbuf[2][TS_MAX];
+  uint32_t cnt[TS_WAVES][TS_RADIX];
+  uint32_t dbase[TS_RADIX];
+  uint32_t qsum[4][TS_RADIX];
+  uint32_t wsum[TS_WAVES];
+  int cut[2];
+};
+
+// Stable LSD radix sort of the m <= TS_MAX (key, value) pairs in L.kbuf[cur] / L.vbuf[cur] by the low
+// 8*passes key bits, entirely in LDS; returns the image that holds the result.  All TS_THREADS
+// threads call this; the caller's fill needs no barrier of its own (the first pass has one) and
+// the result is visible to every thread on return.
+__device__ __forceinline__ int ts_lds_sort(TsLds& L, int m, int passes, int cur) {
+  auto& kbuf = L.kbuf;
+  auto& vbuf = L.vbuf;
+  auto& cnt = L.cnt;
+  auto& dbase = L.dbase;
+  auto& qsum = L.qsum;
+  auto& wsum = L.wsum;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t base_row = toffs[t];
-  const uint32_t rows = (uint32_t) (toffs[t + 1] - base_row);
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  int bits = 0;
-  for (uint32_t v = rows; v; v >>= 1) ++bits;  // values 0..rows
-  const int passes = (bits + 7) / 8;
-  // local key: the id, or `rows` (one past the largest) for a padding / out-of-range entry;
-  // image 0 when the workgroup sorts the whole table, image 1 (scratch) when it first selects
-  const int first = parts > 1 ? 1 : 0;
-#pragma unroll
-  for (int k = 0; k < TS_ITEMS; ++k) {
-    const int e = k * TS_THREADS + tid;
-    if (e < n) {
-      const int b = e / bag_len;
-      const int p = (b * T + t) * bag_len + (e - b * bag_len);
-      const int64_t id = mi_ld_id<IDX>(indices, p);
-      kbuf[first][e] = (id >= 0 && id < (int64_t) rows) ? (uint32_t) id : rows;
-      vbuf[first][e] = (uint32_t) p;
-    }
-  }
-  int m = n, out_base = 0;  // entries this workgroup sorts, and where its output starts in the table's block
-  if (parts > 1) {
-    const int top = bits > 8 ? bits - 8 : 0;  // bin = key >> top, 0..255
-    if (tid < TS_RADIX) dbase[tid] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < TS_ITEMS; ++k) {
-      const int e = k * TS_THREADS + tid;
-      if (e < n) atomicAdd(&dbase[kbuf[1][e] >> top], 1u);  // integer counts: the order of the adds does not matter
-    }
-    __syncthreads();
-    // exclusive prefix of the 256 bin counts -> qsum[0][bin]
-    uint32_t c = tid < TS_RADIX ? dbase[tid] : 0u, inc = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t x = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += x;
-    }
-    if (tid < TS_RADIX && lane == 63) wsum[w] = inc;
-    __syncthreads();
-    if (tid < TS_RADIX) {
-      uint32_t wb = 0;
-      for (int i = 0; i < w; ++i) wb += wsum[i];
-      qsum[0][tid] = wb + inc - c;
-    }
-    __syncthreads();
-    // range q starts at the last bin whose prefix does not exceed q*n/parts (bin 0 for q = 0)
-    if (tid < TS_RADIX) {
-      const uint32_t mine = qsum[0][tid], next = tid + 1 < TS_RADIX ? qsum[0][tid + 1] : 0xFFFFFFFFu;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int q = part + s;
-        if (q > 0 && q < parts) {
-          const uint32_t target = (uint32_t) (((int64_t) q * n) / parts);
-          if (mine <= target && next > target) cut[s] = tid;
-        }
-      }
-    }
-    if (tid == 0) {
-      if (part == 0) cut[0] = 0;
-      if (part == parts - 1) cut[1] = TS_RADIX;
-    }
-    __syncthreads();
-    const int b_lo = cut[0], b_hi = cut[1];
-    out_base = (int) qsum[0][b_lo];
-    m = (b_hi == TS_RADIX ? n : (int) qsum[0][b_hi]) - out_base;
-    // stable selection: entry e of the table keeps its place among the selected ones
-    unsigned long long bal[TS_ITEMS];
-    uint32_t key[TS_ITEMS];
-    const int wbase = w * (MI_WAVE * TS_ITEMS);
-#pragma unroll
-    for (int j = 0; j < TS_ITEMS; ++j) {
-      const int e = wbase + j * MI_WAVE + lane;
-      key[j] = e < n ? kbuf[1][e] : 0u;
-      const int bin = (int) (key[j] >> top);
-      bal[j] = __ballot(e < n && bin >= b_lo && bin < b_hi);
-      if (lane == 0) qsum[1][w * TS_ITEMS + j] = (uint32_t) __popcll(bal[j]);
-    }
-    __syncthreads();
-    if (tid < TS_WAVES * TS_ITEMS) {  // 128 group counts -> exclusive prefix (two waves)
-      const uint32_t g = qsum[1][tid];
-      uint32_t gi = g;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t x = __shfl_up(gi, o, 64);
-        if (lane >= o) gi += x;
-      }
-      if (lane == 63) wsum[w] = gi;
-      qsum[2][tid] = gi - g;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TS_ITEMS; ++j) {
-      const int e = wbase + j * MI_WAVE + lane;
-      if ((bal[j] >> lane) & 1ull) {
-        const int g = w * TS_ITEMS + j;
-        const uint32_t dest = qsum[2][g] + (g >= 64 ? wsum[0] : 0u) + (uint32_t) __popcll(bal[j] & lt);
-        kbuf[0][dest] = key[j];
-        vbuf[0][dest] = vbuf[1][e];
-      }
-    }
-    __syncthreads();
-  }
   // the m entries are spread over all waves: `items` per thread, wave w owns [w*64*items, (w+1)*64*items)
   const int items = (m + TS_THREADS - 1) / TS_THREADS;
   const int wbase = w * MI_WAVE * items;
-  int cur = 0;
   for (int pass = 0; pass < passes && m > 0; ++pass) {
     const int shift = pass * 8;
     for (int i = tid; i < TS_WAVES * TS_RADIX; i += TS_THREADS) (&cnt[0][0])[i] = 0;
@@ -252,7 +157,144 @@ __device__ __forceinline__ void table_sort_body(int t, int part, int parts, cons
     cur ^= 1;
     __syncthreads();  // the scatter is complete (and cnt / dbase free) before the next pass
   }
-  if (passes == 0) __syncthreads();  // a table without rows: the fill above must still be visible
+  return cur;
+}
+
+// The n <= TS_MAX (key, value) pairs of a table lie in image `parts > 1 ? 1 : 0` of L, keys below
+// 2^bits.  Sorts part `part` of `parts` of them (see above) into the returned image, entries
+// [0, m); out_base = how many entries of the table sort before this part's.  All threads call this.
+__device__ __forceinline__ int ts_sort_part(TsLds& L, int n, int part, int parts, int bits, int& m_out,
+                                            int& out_base_out) {
+  auto& kbuf = L.kbuf;
+  auto& vbuf = L.vbuf;
+  auto& dbase = L.dbase;
+  auto& qsum = L.qsum;
+  auto& wsum = L.wsum;
+  auto& cut = L.cut;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int passes = (bits + 7) / 8;
+  int m = n, out_base = 0;  // entries this workgroup sorts, and where its output starts in the table's block
+  if (parts > 1) {
+    const int top = bits > 8 ? bits - 8 : 0;  // bin = key >> top, 0..255
+    if (tid < TS_RADIX) dbase[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TS_ITEMS; ++k) {
+      const int e = k * TS_THREADS + tid;
+      if (e < n) atomicAdd(&dbase[kbuf[1][e] >> top], 1u);  // integer counts: the order of the adds does not matter
+    }
+    __syncthreads();
+    // exclusive prefix of the 256 bin counts -> qsum[0][bin]
+    uint32_t c = tid < TS_RADIX ? dbase[tid] : 0u, inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t x = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += x;
+    }
+    if (tid < TS_RADIX && lane == 63) wsum[w] = inc;
+    __syncthreads();
+    if (tid < TS_RADIX) {
+      uint32_t wb = 0;
+      for (int i = 0; i < w; ++i) wb += wsum[i];
+      qsum[0][tid] = wb + inc - c;
+    }
+    __syncthreads();
+    // range q starts at the last bin whose prefix does not exceed q*n/parts (bin 0 for q = 0)
+    if (tid < TS_RADIX) {
+      const uint32_t mine = qsum[0][tid], next = tid + 1 < TS_RADIX ? qsum[0][tid + 1] : 0xFFFFFFFFu;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int q = part + s;
+        if (q > 0 && q < parts) {
+          const uint32_t target = (uint32_t) (((int64_t) q * n) / parts);
+          if (mine <= target && next > target) cut[s] = tid;
+        }
+      }
+    }
+    if (tid == 0) {
+      if (part == 0) cut[0] = 0;
+      if (part == parts - 1) cut[1] = TS_RADIX;
+    }
+    __syncthreads();
+    const int b_lo = cut[0], b_hi = cut[1];
+    out_base = (int) qsum[0][b_lo];
+    m = (b_hi == TS_RADIX ? n : (int) qsum[0][b_hi]) - out_base;
+    // stable selection: entry e of the table keeps its place among the selected ones
+    unsigned long long bal[TS_ITEMS];
+    uint32_t key[TS_ITEMS];
+    const int wbase = w * (MI_WAVE * TS_ITEMS);
+#pragma unroll
+    for (int j = 0; j < TS_ITEMS; ++j) {
+      const int e = wbase + j * MI_WAVE + lane;
+      key[j] = e < n ? kbuf[1][e] : 0u;
+      const int bin = (int) (key[j] >> top);
+      bal[j] = __ballot(e < n && bin >= b_lo && bin < b_hi);
+      if (lane == 0) qsum[1][w * TS_ITEMS + j] = (uint32_t) __popcll(bal[j]);
+    }
+    __syncthreads();
+    if (tid < TS_WAVES * TS_ITEMS) {  // 128 group counts -> exclusive prefix (two waves)
+      const uint32_t g = qsum[1][tid];
+      uint32_t gi = g;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t x = __shfl_up(gi, o, 64);
+        if (lane >= o) gi += x;
+      }
+      if (lane == 63) wsum[w] = gi;
+      qsum[2][tid] = gi - g;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TS_ITEMS; ++j) {
+      const int e = wbase + j * MI_WAVE + lane;
+      if ((bal[j] >> lane) & 1ull) {
+        const int g = w * TS_ITEMS + j;
+        const uint32_t dest = qsum[2][g] + (g >= 64 ? wsum[0] : 0u) + (uint32_t) __popcll(bal[j] & lt);
+        kbuf[0][dest] = key[j];
+        vbuf[0][dest] = vbuf[1][e];
+      }
+    }
+    __syncthreads();
+  }
+  const int cur = ts_lds_sort(L, m, passes, 0);
+  if (passes == 0) __syncthreads();  // keys of zero bits: the fill must still be visible
+  m_out = m;
+  out_base_out = out_base;
+  return cur;
+}
+
+// Part `part` of `parts` of table `t` is sorted by the calling workgroup (all TS_THREADS threads
+// take part).
+template <typename IDX>
+__device__ __forceinline__ void table_sort_body(int t, int part, int parts, const int64_t* __restrict__ toffs, int T,
+                                                const void* __restrict__ indices, int bag_len, int n,
+                                                uint32_t sentinel, uint32_t* __restrict__ sorted_rows,
+                                                uint32_t* __restrict__ perm) {
+  __shared__ TsLds L;
+  auto& kbuf = L.kbuf;
+  auto& vbuf = L.vbuf;
+  const int tid = threadIdx.x;
+  const int64_t base_row = toffs[t];
+  const uint32_t rows = (uint32_t) (toffs[t + 1] - base_row);
+  int bits = 0;
+  for (uint32_t v = rows; v; v >>= 1) ++bits;  // values 0..rows
+  // local key: the id, or `rows` (one past the largest) for a padding / out-of-range entry;
+  // image 0 when the workgroup sorts the whole table, image 1 (scratch) when it first selects
+  const int first = parts > 1 ? 1 : 0;
+#pragma unroll
+  for (int k = 0; k < TS_ITEMS; ++k) {
+    const int e = k * TS_THREADS + tid;
+    if (e < n) {
+      const int b = e / bag_len;
+      const int p = (b * T + t) * bag_len + (e - b * bag_len);
+      const int64_t id = mi_ld_id<IDX>(indices, p);
+      kbuf[first][e] = (id >= 0 && id < (int64_t) rows) ? (uint32_t) id : rows;
+      vbuf[first][e] = (uint32_t) p;
+    }
+  }
+  int m, out_base;  // entries this workgroup sorts, and where its output starts in the table's block
+  const int cur = ts_sort_part(L, n, part, parts, bits, m, out_base);
   const size_t out = (size_t) t * n + out_base;
 #pragma unroll
   for (int k = 0; k < TS_ITEMS; ++k) {

@@ -472,8 +472,8 @@ def adam_schedule_step(sched, lr, beta1, beta2):
 
 # ----------------------------------------------------------------------------- sharded tables
 def shard_block_ints(B, T):
-    """Ints per rank pair in the row exchange (B+1 offsets, then room for B*T rows)."""
-    return B + 1 + B * T
+    """Ints per rank pair in the row exchange: chunk counts [ceil(B/64)][T], then slots [T][B]."""
+    return -(-B // 64) * T + B * T
 
 
 def shard_row_floats(dim, n_dense):
@@ -488,12 +488,17 @@ def shard_route(toffs, ids, n_ranks, send, err=None):
     _lib.call('mi_shard_route', _p(toffs), T, _p(ids), _idx_bits(ids), B, n_ranks, _p(send), _p(err), _stream())
 
 
-def fm_partial_fwd(table, local_rows, recv, n_ranks, B, T, partial, rows_out, entry_sample, n_out, err=None):
-    if recv.numel() < n_ranks * shard_block_ints(B, T) or min(rows_out.numel(), entry_sample.numel()) < n_ranks * B * T \
-            or partial.numel() < n_ranks * B * (table.dim + 2):
-        raise MiError("fm_partial_fwd: buffer too small")
-    _lib.call('mi_fm_partial_fwd', table.ref(), local_rows, _p(recv), n_ranks, B, T, _p(partial), _p(rows_out),
-              _p(entry_sample), _p(n_out), _p(err), _stream())
+def shard_owner_fwd_sort(table, local_rows, toffs, rank, n_ranks, recv, B, partial, sorted_rows, perm, n_total,
+                         sched, lr, beta1, beta2, err=None):
+    """One launch: partial forward of every (source rank, sample) + sort of the received slots
+    (sorted_rows / perm [N*B*T] and n_total [1]; all None for the forward alone) + Adam schedule."""
+    T = toffs.numel() - 1
+    if recv.numel() < n_ranks * shard_block_ints(B, T) or partial.numel() < n_ranks * B * (table.dim + 2):
+        raise MiError("shard_owner_fwd_sort: buffer too small")
+    if sorted_rows is not None and min(sorted_rows.numel(), perm.numel()) < n_ranks * B * T:
+        raise MiError("shard_owner_fwd_sort: sort output too small")
+    _lib.call('mi_shard_owner_fwd_sort', table.ref(), local_rows, _p(toffs), T, rank, n_ranks, _p(recv), B,
+              _p(partial), _p(sorted_rows), _p(perm), _p(n_total), _p(sched), lr, beta1, beta2, _p(err), _stream())
 
 
 def fm_combine(partials, n_ranks, B, dim, dense, wd, bias, labels, gscale, X, logit=None):
@@ -504,11 +509,21 @@ def fm_combine(partials, n_ranks, B, dim, dense, wd, bias, labels, gscale, X, lo
               gscale, _p(logit), _p(X), X.shape[1], _stream())
 
 
-def fm_bwd_apply_rows(plan, table, X, entry_sample, opt, lr, beta1=0.9, beta2=0.999, eps=1e-8, lr_dev=None):
-    if entry_sample.numel() < plan.n_entries:
-        raise MiError("fm_bwd_apply_rows: entry_sample shorter than the plan")
-    _lib.call('mi_fm_bwd_apply_rows', plan.ref(), table.ref(), _p(X), X.shape[1], _p(entry_sample), opt, lr,
-              _p(lr_dev), beta1, beta2, eps, _stream())
+def shard_dense_scratch_floats(rows, n_dense):
+    return int(_lib.load().mi_shard_dense_scratch_floats(rows, n_dense))
+
+
+def shard_owner_bwd_dense(table, local_rows, sorted_rows, perm, n_total, n_slots, X_all, opt, lr, beta1, beta2, eps, n_dense,
+                          dp, dm, dv, dense_lr_t, scratch, loss_out, lr_dev=None, dense_lr_dev=None):
+    """One launch: sparse backward + fused optimizer over the owner's sorted entries, and the dense
+    side (Adam on dp, mean loss) over all rows of X_all."""
+    rows = X_all.shape[0]
+    if min(sorted_rows.numel(), perm.numel()) < n_slots or scratch.numel() < shard_dense_scratch_floats(rows, n_dense):
+        raise MiError("shard_owner_bwd_dense: buffer too small")
+    _lib.call('mi_shard_owner_bwd_dense', table.ref(), local_rows, _p(sorted_rows), _p(perm), _p(n_total), n_slots,
+              _p(X_all),
+              X_all.shape[1], rows, opt, lr, _p(lr_dev), beta1, beta2, eps, n_dense, _p(dp), _p(dm), _p(dv),
+              dense_lr_t, _p(dense_lr_dev), _p(scratch), _p(loss_out), _stream())
 
 
 def fm_dense_step_rows(X, dim, n_dense, dp, dm, dv, lr_t, beta1, beta2, eps, loss_out, lr_dev=None):

@@ -11,12 +11,18 @@ recommendation/train_job.py:41-42).  That scheme is not reproduced.  Here
   over the N*B samples, and after the step all replicas agree bit for bit.
 
 A step has THREE collectives (RCCL over xGMI through torch.distributed, backend "nccl"), all of
-fixed size, so nothing on the host waits for the device before they are issued:
+fixed size, and FOUR launches; nothing on the host ever waits for the device:
 
-  A. all-to-all  [N][B+1+B*T] int32   requester -> owner: per-sample offsets + the local rows
+  launch 1  route: ids [B][T] -> per owner o: slot[t][b] = local row when o owns it, else -1, and
+            how many valid slots every 64-sample chunk has per table
+  A. all-to-all  [N][blk] int32       requester -> owner (blk = chunk counts + B*T slots)
+  launch 2  owner: partial forward per (source rank, sample) | per-table LDS sort of the valid
+            slots (payload = row of X_all) | Adam schedule step
   B. all-to-all  [N][B][D+2] fp32     owner -> requester: per SAMPLE sum v, sum |v|^2, sum w1
                                       (not per (sample, field))
+  launch 3  combine: sum the owners' partials in rank order, logit, loss, dL/dlogit -> X rows
   C. all-gather  [B][D+2+nd] fp32     every sample's S, dL/dlogit, loss row and dense features
+  launch 4  owner: sparse backward + fused optimizer | dense side over all N*B rows
 
 After C every owner has what its sparse backward needs and every replica computes the dense-side
 gradients of all N*B samples itself, in the same order, so there is no all-reduce.  The sparse
@@ -37,7 +43,7 @@ def local_row_count(total_rows, rank, world):
 
 
 class HipBackend(object):
-    """Local compute of one rank: every method is one or two C-ABI calls."""
+    """Local compute of one rank: every step piece is one C-ABI call, one launch."""
 
     def __init__(self, rows_per_table, dim, n_dense, device, opt, rank, world):
         self.device = torch.device(device)
@@ -47,11 +53,7 @@ class HipBackend(object):
         self.local_rows = local_row_count(self.total_rows, rank, world)
         self.toffs = ops.table_offsets(rows_per_table, self.device)
         self.table = ops.FmRecords(max(self.local_rows, 1), dim, _OPT[opt], self.device)
-        self.local_toffs = ops.table_offsets([max(self.local_rows, 1)], self.device)
         self.err = ops.new_error_word(self.device)
-        self.plan = None
-        self.n_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self.n_ready = torch.cuda.Event()
 
     # parameters ------------------------------------------------------------------------------
     def init_rows(self, V, w1):
@@ -65,39 +67,26 @@ class HipBackend(object):
     def zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
-    # step pieces -----------------------------------------------------------------------------
+    def dense_scratch(self, rows):
+        return self.zeros((ops.shard_dense_scratch_floats(rows, self.n_dense),), torch.float32)
+
+    # step pieces: one launch each ---------------------------------------------------------------
     def route(self, ids, send):
         ops.shard_route(self.toffs, ids, self.world, send, self.err)
 
-    def partial_fwd(self, recv, B, partial, rows_out, entry_sample, n_dev):
-        ops.fm_partial_fwd(self.table, self.local_rows, recv, self.world, B, self.T, partial, rows_out,
-                           entry_sample, n_dev, self.err)
-        # the number of received rows travels to the host behind the kernel; it is only needed
-        # when the backward is enqueued, two collectives later
-        self.n_host.copy_(n_dev, non_blocking=True)
-        self.n_ready.record()
-
-    def received(self):
-        self.n_ready.synchronize()
-        return int(self.n_host[0])
+    def owner_forward(self, recv, B, partial, sorted_rows, perm, n_total, sched, lr, beta1, beta2):
+        ops.shard_owner_fwd_sort(self.table, max(self.local_rows, 1), self.toffs, self.rank, self.world, recv, B,
+                                 partial, sorted_rows, perm, n_total, sched, lr, beta1, beta2, self.err)
 
     def combine(self, partials, B, dense, wd, bias, labels, gscale, X):
         ops.fm_combine(partials, self.world, B, self.dim, dense, wd, bias, labels, gscale, X)
 
-    def dense_step(self, X_all, dp, dm, dv, lr, beta1, beta2, eps, sched, loss):
-        ops.adam_schedule_step(sched, lr, beta1, beta2)
-        ops.fm_dense_step_rows(X_all, self.dim, self.n_dense, dp, dm, dv, 0.0, beta1, beta2, eps, loss,
-                               lr_dev=sched)
-
-    def owner_backward(self, rows, n_recv, entry_sample, X_all, lr, beta1, beta2, eps, sched):
-        if n_recv == 0:
-            return
-        if self.plan is None or self.plan.indices.data_ptr() != rows.data_ptr():
-            self.plan = ops.SortedPlan(self.local_toffs, 1, max(self.local_rows, 1), rows, bag_len=1, runs=False)
-        self.plan.prepare_prefix(n_recv)
+    def update(self, sorted_rows, perm, n_total, X_all, dp, dm, dv, lr, beta1, beta2, eps, sched, scratch, loss):
         adam = self.opt == 'adam_tf'
-        ops.fm_bwd_apply_rows(self.plan, self.table, X_all, entry_sample, _OPT[self.opt], lr, beta1, beta2, eps,
-                              lr_dev=sched if adam else None)
+        ops.shard_owner_bwd_dense(self.table, max(self.local_rows, 1), sorted_rows, perm, n_total,
+                                  sorted_rows.numel(), X_all,
+                                  _OPT[self.opt], lr, beta1, beta2, eps, self.n_dense, dp, dm, dv, 0.0, scratch, loss,
+                                  lr_dev=sched if adam else None, dense_lr_dev=sched)
 
     def check(self):
         ops.check_error_word(self.err, "sharded FM ids")
@@ -175,16 +164,17 @@ class ShardedFactorizationMachine(object):
     def _buffers(self, B):
         if self._B == B:
             return
-        N, D, be = self.world, self.dim, self.be
+        N, D, T, be = self.world, self.dim, self.T, self.be
         i32, f32 = torch.int32, torch.float32
-        blk = ops.shard_block_ints(B, self.T)
         self.ld = ops.shard_row_floats(D, self.n_dense)
+        blk = ops.shard_block_ints(B, T)
         self.send, self.recv = be.zeros((N, blk), i32), be.zeros((N, blk), i32)
-        cap = N * B * self.T                       # an owner can at most receive every entry of every rank
-        self.rows_in, self.entry_sample = be.zeros((cap,), i32), be.zeros((cap,), i32)
-        self.n_dev = be.zeros((1,), i32)
+        # room for every entry of every rank (an owner can receive them all)
+        self.sorted_rows, self.perm = be.zeros((N * B * T,), i32), be.zeros((N * B * T,), i32)
+        self.n_total = be.zeros((1,), i32)
         self.partial, self.partials_in = be.zeros((N, B, D + 2), f32), be.zeros((N, B, D + 2), f32)
         self.X, self.X_all = be.zeros((B, self.ld), f32), be.zeros((N * B, self.ld), f32)
+        self.scratch = be.dense_scratch(N * B)
         self.loss = be.zeros((1,), f32)
         self._B = B
 
@@ -196,8 +186,10 @@ class ShardedFactorizationMachine(object):
         return self.send
 
     def phase_owner_forward(self):
-        """self.recv -> self.partial [N][B][D+2] (exchange B: all-to-all into self.partials_in)."""
-        self.be.partial_fwd(self.recv, self._B, self.partial, self.rows_in, self.entry_sample, self.n_dev)
+        """self.recv -> self.partial [N][B][D+2] (exchange B: all-to-all into self.partials_in), and
+        the sorted entries the backward will take."""
+        self.be.owner_forward(self.recv, self._B, self.partial, self.sorted_rows, self.perm, self.n_total, self.sched,
+                              self.lr, self.beta1, self.beta2)
         return self.partial
 
     def phase_combine(self, dense, labels):
@@ -208,11 +200,9 @@ class ShardedFactorizationMachine(object):
         return self.X
 
     def phase_update(self):
-        """Dense step on every replica, sparse backward + optimizer on the owner."""
-        self.be.dense_step(self.X_all, self.dp, self.dm, self.dv, self.lr, self.beta1, self.beta2, self.eps,
-                           self.sched, self.loss)
-        self.be.owner_backward(self.rows_in, self.be.received(), self.entry_sample, self.X_all, self.lr, self.beta1,
-                               self.beta2, self.eps, self.sched)
+        """Sparse backward + optimizer on the owner, dense step on every replica."""
+        self.be.update(self.sorted_rows, self.perm, self.n_total, self.X_all, self.dp, self.dm, self.dv, self.lr,
+                       self.beta1, self.beta2, self.eps, self.sched, self.scratch, self.loss)
 
     # -- one step over torch.distributed --------------------------------------------------------
     def train_step(self, ids, dense, labels, check_ids=False):

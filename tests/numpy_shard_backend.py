@@ -35,43 +35,57 @@ class NumpyBackend(object):
     def zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype)
 
+    def dense_scratch(self, rows):
+        return torch.zeros((1,), dtype=torch.float32)
+
+    def first_local(self, t):
+        return (int(self.toffs[t]) - self.rank + self.world - 1) // self.world
+
+    def _split(self, block, B):
+        """block [blk] -> (cnt [n_chunks][T], slots [T][B])"""
+        nc = -(-B // 64)
+        return block[:nc * self.T].reshape(nc, self.T), block[nc * self.T:].reshape(self.T, B)
+
     def route(self, ids, send):
         ids = _np(ids).astype(np.int64)
         B = ids.shape[0]
-        g = ids + self.toffs[:-1][None, :]
-        out = _np(send)
+        g = ids + self.toffs[:-1][None, :]                      # [B][T]
+        out = _np(send)                                          # [N][blk]
         for d in range(self.world):
-            mask = (g % self.world) == d
-            out[d, 0] = 0
-            out[d, 1:B + 1] = np.cumsum(mask.sum(1))
-            loc = (g // self.world)[mask]                        # row-major: sample, then field
-            out[d, B + 1:B + 1 + loc.size] = loc
+            cnt, slots = self._split(out[d], B)
+            mine = (g % self.world) == d
+            slots[:] = np.where(mine, g // self.world, -1).T
+            for c in range(cnt.shape[0]):
+                cnt[c] = mine[64 * c:64 * c + 64].sum(0)
 
-    def partial_fwd(self, recv, B, partial, rows_out, entry_sample, n_dev):
+    def owner_forward(self, recv, B, partial, sorted_rows, perm, n_total, sched, lr, beta1, beta2):
         R, P = _np(recv), _np(partial)
-        ro, es = _np(rows_out), _np(entry_sample)
-        P[:] = 0
+        slots_all = np.stack([self._split(R[s], B)[1] for s in range(self.world)])   # [N][T][B]
         D = self.dim
-        base = 0
+        P[:] = 0
         for s in range(self.world):
-            off, rows = R[s, :B + 1], R[s, B + 1:]
             for b in range(B):
-                lo, hi = off[b], off[b + 1]
-                if hi == lo:
+                seg = slots_all[s, :, b]
+                seg = seg[seg >= 0]
+                if seg.size == 0:
                     continue
-                seg = rows[lo:hi]
                 v = self.V[seg]
                 P[s, b, :D] = v.sum(0, dtype=np.float32)
                 P[s, b, D] = (v * v).sum(dtype=np.float32)
                 P[s, b, D + 1] = self.w1[seg].sum(dtype=np.float32)
-                ro[base + lo:base + hi] = seg
-                es[base + lo:base + hi] = s * B + b
-            base += off[B]
-        _np(n_dev)[0] = base
-        self._n = int(base)
-
-    def received(self):
-        return self._n
+        so, pe = _np(sorted_rows), _np(perm)
+        at = 0
+        for t in range(self.T):
+            slots = slots_all[:, t, :].reshape(-1)               # stream order e = s*B + b
+            e = np.nonzero(slots >= 0)[0]
+            order = np.argsort(slots[e], kind='stable')
+            n = e.size
+            assert np.all(slots[e] >= self.first_local(t)) and np.all(slots[e] < self.first_local(t + 1))
+            assert n == sum(int(self._split(R[s], B)[0][:, t].sum()) for s in range(self.world))
+            so[at:at + n], pe[at:at + n] = slots[e][order], e[order]
+            at += n
+        _np(n_total)[0] = at
+        _np(sched)[3] += 1
 
     def combine(self, partials, B, dense, wd, bias, labels, gscale, X):
         P = _np(partials)
@@ -92,29 +106,24 @@ class NumpyBackend(object):
         if dense is not None:
             x[:, D + 2:D + 2 + self.n_dense] = _np(dense)
 
-    def dense_step(self, X_all, dp, dm, dv, lr, beta1, beta2, eps, sched, loss):
+    def update(self, sorted_rows, perm, n_total, X_all, dp, dm, dv, lr, beta1, beta2, eps, sched, scratch, loss):
         x = _np(X_all)
         D, nd = self.dim, self.n_dense
         g = x[:, D]
         grad = np.concatenate([g @ x[:, D + 2:D + 2 + nd], [g.sum(dtype=np.float32)]]).astype(np.float32)
         _np(loss)[0] = x[:, D + 1].mean(dtype=np.float32)
-        s = _np(sched)
-        s[3] += 1
-        alpha, omb1, omb2 = oemb.tf_adam_scalars(lr, beta1, beta2, int(s[3]))
+        alpha, omb1, omb2 = oemb.tf_adam_scalars(lr, beta1, beta2, int(_np(sched)[3]))
         w, m, v = oemb.adam_tf_update(_np(dp).copy(), _np(dm).copy(), _np(dv).copy(), grad, alpha, omb1, omb2, eps)
         _np(dp)[:], _np(dm)[:], _np(dv)[:] = w, m, v
-
-    def owner_backward(self, rows, n_recv, entry_sample, X_all, lr, beta1, beta2, eps, sched):
-        if n_recv == 0:
-            return
-        rows, es = _np(rows)[:n_recv].astype(np.int64), _np(entry_sample)[:n_recv]
-        x = _np(X_all)
-        ga, Sa = x[:, self.dim], x[:, :self.dim]
-        order = np.argsort(rows, kind='stable')
-        uniq, start = np.unique(rows[order], return_index=True)
-        end = np.append(start[1:], n_recv)
+        # sparse side: runs of equal rows in the sorted entries, padding skipped
+        n = int(_np(n_total)[0])
+        ga, Sa = x[:, D], x[:, :D]
+        rows, es = _np(sorted_rows)[:n].astype(np.int64), _np(perm)[:n]
+        uniq, start = np.unique(rows, return_index=True)
+        assert np.all(np.diff(rows) >= 0)
+        end = np.append(start[1:], rows.size)
         for u, lo, hi in zip(uniq, start, end):
-            e = es[order[lo:hi]]
+            e = es[lo:hi]
             gv = (ga[e, None] * (Sa[e] - self.V[u][None, :])).sum(0, dtype=np.float32)
             gw = ga[e].sum(dtype=np.float32)
             if self.opt == 'sgd':
