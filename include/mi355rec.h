@@ -143,7 +143,7 @@ typedef struct mi_bwd_plan {
   int bag_len;
   int T;
   int pool_mode;
-  int32_t* long_list; /* scratch, n_entries + 2 ints, first two zeroed once by the caller */
+  int32_t* long_list; /* scratch, n_entries + 2 ints, zeroed once by the caller (the calls leave it zero) */
   /* needed for MI_POOL_MEAN only (the bag's count of valid ids); may be NULL for sum */
   const void* indices;
   int idx_bits;
@@ -362,9 +362,9 @@ int mi_fm_combine(const float* partials, int n_ranks, int64_t B, int dim, const 
  * from X_all[rows][ld]; and the dense side over ALL rows of X_all: every replica computes the
  * dense-side gradients of all N*B samples itself, in the same order on every rank, so replicas
  * stay bit-identical without an all-reduce; TensorFlow-form Adam on dp[n_dense+1] = {wd, bias},
- * loss_out[0] = mean of the loss column.  scratch: mi_shard_dense_scratch_floats(rows, n_dense)
- * floats, zeroed once by the caller. */
-int64_t mi_shard_dense_scratch_floats(int64_t rows, int n_dense);
+ * loss_out[0] = mean of the loss column.  scratch: mi_shard_bwd_scratch_floats(rows, n_dense,
+ * n_slots) floats, zeroed once by the caller. */
+int64_t mi_shard_bwd_scratch_floats(int64_t rows, int n_dense, int64_t n_slots);
 int mi_shard_owner_bwd_dense(const mi_fm_table* tab, int64_t local_rows, const uint32_t* sorted_rows,
                              const int32_t* perm, const int32_t* n_total, int64_t n_slots, const float* X, int ld,
                              int64_t rows, int opt, float lr, const float* lr_dev, float beta1,

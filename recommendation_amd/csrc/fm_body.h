@@ -235,10 +235,29 @@ __device__ __forceinline__ void fm_dense_rows_body(const FmDenseRowsArgs& a, int
   __syncthreads();
   if (!last) return;
   __threadfence();
+  // same shape as above over the partials: thread (rr, j) adds chunks rr, rr+rl, ... (loads issued in
+  // batches of eight), then the tree over rr
+  float tot = 0.f;
+  for (int c0 = rr; c0 < a.chunks; c0 += 8 * rl) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + u * rl;
+      v[u] = c < a.chunks ? __builtin_nontemporal_load(a.part + (size_t) c * ct + j) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tot += v[u];
+  }
+  __syncthreads();
+  sh[threadIdx.x] = tot;
+  __syncthreads();
+  for (int s = rl / 2; s > 0; s >>= 1) {
+    if (rr < s) sh[threadIdx.x] += sh[threadIdx.x + s * ct];
+    __syncthreads();
+  }
   if ((int) threadIdx.x < a.n_dense + 2) {
     const int k = threadIdx.x;
-    float tot = 0.f;
-    for (int c = 0; c < a.chunks; ++c) tot += __builtin_nontemporal_load(a.part + (size_t) c * ct + k);
+    tot = sh[k];
     if (k == a.n_dense + 1) {
       a.loss_out[0] = tot / (float) a.rows;
     } else {

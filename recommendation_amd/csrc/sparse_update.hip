@@ -37,6 +37,7 @@ struct PlanDev {
   const int32_t* counts;
   int32_t* long_list;  // [0] count, [1] finished-workgroup ticket, [2..] queued runs
   const int32_t* n_dev;  // when set, the number of entries is read from the device (n is then its upper bound)
+  int split;             // long runs are summed piecewise by several workgroups (long_list has room for the partials)
   const int64_t* offsets;
   const void* indices;
   const int64_t* toffs;
@@ -320,6 +321,30 @@ __device__ __forceinline__ int run_end_wave(const uint32_t* keys, int n, int beg
   return lo;
 }
 
+// Start of the run of `row` that contains entry `at` (first index of the contiguous stretch of
+// entries equal to row that ends at `at`), found by one wave the same way, looking backwards.
+__device__ __forceinline__ int run_begin_wave(const uint32_t* keys, int at, uint32_t row) {
+  const int lane = threadIdx.x & 63;
+  int lo = 0, hi = at;  // answer in [lo, hi]: keys[hi] == row
+  bool first = true;
+  while (lo < hi) {
+    const int span = hi - lo;
+    int step = (span + 63) / 64;
+    if (first && step > 16) step = 16;
+    first = false;
+    const int idx = hi - (lane + 1) * step;  // lane 0 nearest to hi
+    const bool ne = idx < lo || keys[idx] != row;
+    const unsigned long long m = __ballot(ne);   // monotone in the lane: 0..0 1..1
+    const int f = m ? __ffsll((long long) m) - 1 : 64;
+    // lanes < f are still inside the run; lane f (if any) is outside
+    const int new_hi = f > 0 ? hi - f * step : hi;
+    const int new_lo = f < 64 ? max(lo, hi - (f + 1) * step + 1) : lo;
+    lo = new_lo;
+    hi = new_hi;
+  }
+  return lo;
+}
+
 // One wave sums the run [beg, end) of `row`: its 64/lanes lane groups stride over the entries,
 // then a fixed shuffle tree combines them and group 0 applies the update.  Every lane of the
 // wave must call this together.  Needs lanes to be a power of two <= 64.
@@ -462,26 +487,17 @@ __device__ __forceinline__ int kth_set_bit(unsigned long long m, int k) {
   return pos;
 }
 
-// One workgroup sums the run of `row` that starts at `beg` (end looked up unless given): its lane
-// groups stride over the entries and combine partial sums through a fixed LDS tree.  The order of
-// additions depends only on the run's length: reproducible bit for bit.  All threads call this.
-template <int VEC, class Src, class Upd>
-__device__ __forceinline__ void block_run(const PlanDev& pl, const Src& src, const Upd& upd, int lanes, int groups,
-                                          int beg, int end, uint32_t row, float* red, float* reds, int* sh_end) {
+// One workgroup sums the entries [beg, end): its lane groups stride over them and combine partial
+// sums through a fixed LDS tree, leaving the totals in red[c*VEC + k] / reds[c] (c < lanes).  The
+// order of additions depends only on the number of entries: reproducible bit for bit.  All threads
+// call this; the totals are visible to all on return.
+template <int VEC, class Src>
+__device__ __forceinline__ void block_sum(const PlanDev& pl, const Src& src, int lanes, int groups, int beg, int end,
+                                          float* red, float* reds) {
   const int sub = threadIdx.x / lanes, c = threadIdx.x - sub * lanes;
   const bool active = sub < groups;
   int top = 1;
   while (top < groups) top <<= 1;
-  if (end < 0) {
-    if (threadIdx.x < 64) {
-      const int e = run_end_wave(pl.sorted_rows, pl.n, beg, row);
-      if (threadIdx.x == 0) *sh_end = e;
-    }
-    __syncthreads();
-    end = *sh_end;
-  }
-  typename Upd::template Regs<VEC> regs;
-  if (sub == 0) upd.template load<VEC>((int64_t) row, c, regs);
   float acc[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
@@ -501,6 +517,25 @@ __device__ __forceinline__ void block_run(const PlanDev& pl, const Src& src, con
     }
     __syncthreads();
   }
+}
+
+// One workgroup sums the run of `row` that starts at `beg` (end looked up unless given) and applies
+// the update.  All threads call this.
+template <int VEC, class Src, class Upd>
+__device__ __forceinline__ void block_run(const PlanDev& pl, const Src& src, const Upd& upd, int lanes, int groups,
+                                          int beg, int end, uint32_t row, float* red, float* reds, int* sh_end) {
+  const int sub = threadIdx.x / lanes, c = threadIdx.x - sub * lanes;
+  if (end < 0) {
+    if (threadIdx.x < 64) {
+      const int e = run_end_wave(pl.sorted_rows, pl.n, beg, row);
+      if (threadIdx.x == 0) *sh_end = e;
+    }
+    __syncthreads();
+    end = *sh_end;
+  }
+  typename Upd::template Regs<VEC> regs;
+  if (sub == 0) upd.template load<VEC>((int64_t) row, c, regs);
+  block_sum<VEC>(pl, src, lanes, groups, beg, end, red, reds);
   if (sub == 0) {
     float g[VEC];
 #pragma unroll
@@ -524,6 +559,7 @@ __device__ __forceinline__ void block_run(const PlanDev& pl, const Src& src, con
 // i+WAVE_MAX's) and sums those with all its threads.  They are dispatched first and work beside
 // the short runs instead of after them; nothing is queued, no atomics on global memory.
 constexpr int LONG_CHUNK = 1024;
+constexpr int SPLIT_MIN = 4 * LONG_CHUNK;  // runs longer than this are summed piecewise by several workgroups
 constexpr int LONG_CAP = LONG_CHUNK / (WAVE_MAX + 1) + 2;  // heads of long runs are more than WAVE_MAX apart
 
 //
@@ -546,7 +582,7 @@ struct FmDenseRowsExtra {
 };
 static_assert(FM_DENSE_THREADS == UBLOCK, "the dense side runs in workgroups of the sparse update's size");
 
-template <int VEC, class Src, class Upd, class Extra>
+template <int VEC, bool SPLIT, class Src, class Upd, class Extra>
 __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src, Upd upd, int lanes, int groups,
                                                            int long_blocks, Extra extra) {
   if (pl.n_dev) pl.n = min(pl.n, pl.n_dev[0]);
@@ -561,17 +597,29 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
   if (bid < long_blocks) {
     __shared__ float red[UBLOCK * VEC];
     __shared__ float reds[UBLOCK];
-    __shared__ int sh_end, sh_n, sh_heads[LONG_CAP];
+    __shared__ int sh_end, sh_n, sh_heads[LONG_CAP], sh_span[2], sh_last;
     if (threadIdx.x == 0) sh_n = 0;
     __syncthreads();
     const int lo = bid * LONG_CHUNK;
+    if (lo >= pl.n) return;  // uniform
     const int hi = lo + LONG_CHUNK < pl.n ? lo + LONG_CHUNK : pl.n;
+    // what decides whether a run of more than SPLIT_MIN entries enters from the left (it then covers
+    // lo - SPLIT_MIN/2 or lo + SPLIT_MIN/2), requested now so that the answer is there when needed
+    uint32_t k_lo = 0, k_prev = 1, k_far_l = 1, k_far_r = 1;
+    if (SPLIT) {
+      k_lo = keys[lo];
+      k_prev = lo > 0 ? keys[lo - 1] : ~k_lo;
+      k_far_l = lo >= SPLIT_MIN / 2 ? keys[lo - SPLIT_MIN / 2] : ~k_lo;
+      k_far_r = lo + SPLIT_MIN / 2 < pl.n ? keys[lo + SPLIT_MIN / 2] : ~k_lo;
+    }
     for (int i = lo + threadIdx.x; i < hi; i += UBLOCK) {
       if (i + WAVE_MAX >= pl.n) break;
       const uint32_t key = keys[i];
       if (key == sentinel || keys[i + WAVE_MAX] != key) continue;
       if (i > 0 && keys[i - 1] == key) continue;
-      sh_heads[atomicAdd(&sh_n, 1)] = i;
+      // bit 30 marks a run of more than SPLIT_MIN entries (positions are below 2^30: see the host check)
+      const bool big = SPLIT && i + SPLIT_MIN < pl.n && keys[i + SPLIT_MIN] == key;
+      sh_heads[atomicAdd(&sh_n, 1)] = i | (big ? (1 << 30) : 0);
     }
     __syncthreads();
     const int nh = sh_n;
@@ -579,14 +627,85 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
       for (int x = 1; x < nh; ++x) {
         const int v = sh_heads[x];
         int y = x - 1;
-        for (; y >= 0 && sh_heads[y] > v; --y) sh_heads[y + 1] = sh_heads[y];
+        for (; y >= 0 && (sh_heads[y] & ~(1 << 30)) > (v & ~(1 << 30)); --y) sh_heads[y + 1] = sh_heads[y];
         sh_heads[y + 1] = v;
       }
     }
     __syncthreads();
-    for (int h = 0; h < nh; ++h) {
-      const int head = sh_heads[h];
-      block_run<VEC>(pl, src, upd, lanes, groups, head, -1, keys[head], red, reds, &sh_end);
+    // A long run is summed in pieces, one per LONG_CHUNK it touches, each by the workgroup of that
+    // chunk, so that a row hit by a large part of the batch does not keep ONE workgroup busy while
+    // the rest of the chip is done.  Piece h = -1: the run that enters this chunk from the left.
+    const int sub = threadIdx.x / lanes, c = threadIdx.x - sub * lanes;
+    const int dimv = lanes * VEC + 1;  // floats of a partial: the vector sum and the scalar
+    int32_t* ticket = pl.long_list + 2;
+    float* parts = reinterpret_cast<float*>(pl.long_list + 2 + long_blocks);
+    for (int h = SPLIT ? -1 : 0; h < nh; ++h) {  // uniform
+      int beg, piece_lo;
+      uint32_t row;
+      if (h < 0) {
+        row = k_lo;
+        if (row == sentinel || k_prev != row) continue;  // nothing enters from the left
+        if (k_far_l != row && k_far_r != row) continue;  // nothing long enough to be shared
+        if (threadIdx.x < 64) {
+          const int b = run_begin_wave(keys, lo, row);
+          if (threadIdx.x == 0) sh_span[0] = b;
+        }
+        piece_lo = lo;
+      } else {
+        piece_lo = sh_heads[h] & ~(1 << 30);
+        row = keys[piece_lo];
+        if (!SPLIT || !(sh_heads[h] >> 30)) {  // the whole run is this workgroup's
+          block_run<VEC>(pl, src, upd, lanes, groups, piece_lo, -1, row, red, reds, &sh_end);
+          continue;
+        }
+        if (threadIdx.x == 0) sh_span[0] = piece_lo;
+      }
+      if (threadIdx.x < 64) {
+        const int e = run_end_wave(keys, pl.n, piece_lo, row);
+        if (threadIdx.x == 0) sh_span[1] = e;
+      }
+      __syncthreads();
+      beg = sh_span[0];
+      const int end = sh_span[1];
+      __syncthreads();  // sh_span is rewritten by the next piece
+      if (end - beg <= WAVE_MAX) continue;  // a short run that straddles the chunk border: the waves' job
+      const int first_chunk = beg / LONG_CHUNK, last_chunk = (end - 1) / LONG_CHUNK;
+      // Every workgroup that meets the run takes the same decision from (beg, end).  Pieces cost a
+      // device-wide fence each, so only runs of several chunks are split; the others belong to the
+      // workgroup of the chunk they start in.
+      if (end - beg <= SPLIT_MIN) continue;  // (a run entering from the left that its head's workgroup sums alone)
+      const int piece_hi = end < lo + LONG_CHUNK ? end : lo + LONG_CHUNK;
+      block_sum<VEC>(pl, src, lanes, groups, piece_lo, piece_hi, red, reds);
+      float* mine = parts + ((size_t) bid * 2 + (h < 0 ? 0 : 1)) * dimv;
+      if (sub == 0) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) mine[c * VEC + k] = red[c * VEC + k];
+        if (c == 0) mine[dimv - 1] = reds[0];
+      }
+      __threadfence();  // the partial is visible device-wide before the ticket is taken
+      __syncthreads();
+      if (threadIdx.x == 0) sh_last = atomicAdd(&ticket[first_chunk], 1) == last_chunk - first_chunk ? 1 : 0;
+      __syncthreads();
+      if (!sh_last) continue;
+      __threadfence();
+      // the last piece to arrive adds the partials in position order and applies the update
+      if (sub == 0) {
+        typename Upd::template Regs<VEC> regs;
+        upd.template load<VEC>((int64_t) row, c, regs);
+        float g[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) g[k] = 0.f;
+        float gs = 0.f;
+        for (int ch = first_chunk; ch <= last_chunk; ++ch) {
+          const float* p = parts + ((size_t) ch * 2 + (ch == first_chunk ? 1 : 0)) * dimv;
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) g[k] += __builtin_nontemporal_load(p + c * VEC + k);
+          gs += __builtin_nontemporal_load(p + dimv - 1);
+        }
+        upd.template finish<VEC>((int64_t) row, c, lanes, regs, g, gs);
+      }
+      if (threadIdx.x == 0) atomicExch(&ticket[first_chunk], 0);
+      __syncthreads();
     }
     return;
   }
@@ -718,6 +837,7 @@ int check_plan(const mi_bwd_plan* plan, PlanDev* pl, bool need_runs, const char*
   pl->counts = plan->counts;
   pl->long_list = plan->long_list;
   pl->n_dev = nullptr;
+  pl->split = 0;
   pl->offsets = plan->offsets;
   pl->indices = plan->indices;
   pl->toffs = plan->table_offsets;
@@ -752,13 +872,24 @@ int run_segments(const mi_bwd_plan* plan, const PlanDev& pl, const Src& src, con
       return MI_ERR_UNSUPPORTED;
     }
     const int long_blocks = (int) mi_cdiv(plan->n_entries, LONG_CHUNK);
+    // piecewise long runs need tickets and two partials per chunk behind the two header words of long_list
+    PlanDev pls = pl;
+    // ... and are only worth their extra work when one row can collect several times SPLIT_MIN
+    // entries: with fixed-width bags a row gets at most the n_entries / T entries of its table
+    const int64_t per_table = plan->offsets ? plan->n_entries : plan->n_entries / plan->T;
+    pls.split = (int64_t) long_blocks * (1 + 2 * (g.lanes * g.vec + 1)) <= plan->n_entries &&
+                        plan->n_entries < ((int64_t) 1 << 30) && per_table > 2 * SPLIT_MIN
+                    ? 1 : 0;
     const unsigned grid = (unsigned) (extra.blocks + long_blocks + mi_cdiv(plan->n_entries, UBLOCK));
-    if (g.vec == 4)
-      hipLaunchKernelGGL((seg_sorted_kernel<4, Src, Upd, Extra>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes,
-                         g.gpb, long_blocks, extra);
-    else
-      hipLaunchKernelGGL((seg_sorted_kernel<1, Src, Upd, Extra>), dim3(grid), dim3(UBLOCK), 0, s, pl, src, upd, g.lanes,
-                         g.gpb, long_blocks, extra);
+#define SEG_LAUNCH(V, SP)                                                                                              \
+  hipLaunchKernelGGL((seg_sorted_kernel<V, SP, Src, Upd, Extra>), dim3(grid), dim3(UBLOCK), 0, s, pls, src, upd, g.lanes, \
+                     g.gpb, long_blocks, extra)
+    if (g.vec == 4) {
+      if (pls.split) SEG_LAUNCH(4, true); else SEG_LAUNCH(4, false);
+    } else {
+      if (pls.split) SEG_LAUNCH(1, true); else SEG_LAUNCH(1, false);
+    }
+#undef SEG_LAUNCH
     MI_LAUNCH_CHECK();
     return MI_OK;
   }
@@ -914,11 +1045,13 @@ extern "C" int mi_fm_bwd_apply(const mi_bwd_plan* plan, const mi_fm_table* tab, 
                            beta2, eps, stream, NoExtra{0});
 }
 
-extern "C" int64_t mi_shard_dense_scratch_floats(int64_t rows, int n_dense) {
+static int64_t dense_rows_chunks(int64_t rows) { return rows < 1 ? 1 : (rows + 255) / 256 > 512 ? 512 : (rows + 255) / 256; }
+
+extern "C" int64_t mi_shard_bwd_scratch_floats(int64_t rows, int n_dense, int64_t n_slots) {
   int ct = 1;
   while (ct < n_dense + 2) ct <<= 1;
-  const int64_t chunks = rows < 1 ? 1 : (rows + 255) / 256 > 512 ? 512 : (rows + 255) / 256;
-  return chunks * ct + 1;  // partials + the ticket word
+  // the sparse update's long-run scratch (n_slots + 2 words), then the dense side's partials and ticket
+  return (n_slots + 2) + dense_rows_chunks(rows) * ct + 1;
 }
 
 extern "C" int mi_shard_owner_bwd_dense(const mi_fm_table* tab, int64_t local_rows, const uint32_t* sorted_rows,
@@ -937,7 +1070,8 @@ extern "C" int mi_shard_owner_bwd_dense(const mi_fm_table* tab, int64_t local_ro
   mi_bwd_plan plan = {};
   plan.sorted_rows = sorted_rows;
   plan.perm = perm;
-  plan.long_list = reinterpret_cast<int32_t*>(scratch);  // required non-NULL; a plan without run arrays never uses it
+  plan.long_list = reinterpret_cast<int32_t*>(scratch);
+  scratch += n_slots + 2;
   plan.T = 1;  // entry p's sample is p itself: the sort's payload is the row of X
   plan.n_entries = n_slots;
   plan.n_bags = n_slots;
@@ -948,7 +1082,7 @@ extern "C" int mi_shard_owner_bwd_dense(const mi_fm_table* tab, int64_t local_ro
   FmDenseRowsArgs& a = extra.a;
   a.ct = 1;
   while (a.ct < n_dense + 2) a.ct <<= 1;
-  a.chunks = (int) (mi_shard_dense_scratch_floats(rows, n_dense) - 1) / a.ct;
+  a.chunks = (int) dense_rows_chunks(rows);
   extra.blocks = a.chunks;
   a.X = X; a.ld = ld; a.rows = rows; a.dim = tab->dim; a.n_dense = n_dense;
   a.part = scratch;

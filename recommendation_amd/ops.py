@@ -509,8 +509,8 @@ def fm_combine(partials, n_ranks, B, dim, dense, wd, bias, labels, gscale, X, lo
               gscale, _p(logit), _p(X), X.shape[1], _stream())
 
 
-def shard_dense_scratch_floats(rows, n_dense):
-    return int(_lib.load().mi_shard_dense_scratch_floats(rows, n_dense))
+def shard_bwd_scratch_floats(rows, n_dense, n_slots):
+    return int(_lib.load().mi_shard_bwd_scratch_floats(rows, n_dense, n_slots))
 
 
 def shard_owner_bwd_dense(table, local_rows, sorted_rows, perm, n_total, n_slots, X_all, opt, lr, beta1, beta2, eps, n_dense,
@@ -518,7 +518,7 @@ def shard_owner_bwd_dense(table, local_rows, sorted_rows, perm, n_total, n_slots
     """One launch: sparse backward + fused optimizer over the owner's sorted entries, and the dense
     side (Adam on dp, mean loss) over all rows of X_all."""
     rows = X_all.shape[0]
-    if min(sorted_rows.numel(), perm.numel()) < n_slots or scratch.numel() < shard_dense_scratch_floats(rows, n_dense):
+    if min(sorted_rows.numel(), perm.numel()) < n_slots or scratch.numel() < shard_bwd_scratch_floats(rows, n_dense, n_slots):
         raise MiError("shard_owner_bwd_dense: buffer too small")
     _lib.call('mi_shard_owner_bwd_dense', table.ref(), local_rows, _p(sorted_rows), _p(perm), _p(n_total), n_slots,
               _p(X_all),

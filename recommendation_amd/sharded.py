@@ -67,8 +67,8 @@ class HipBackend(object):
     def zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
-    def dense_scratch(self, rows):
-        return self.zeros((ops.shard_dense_scratch_floats(rows, self.n_dense),), torch.float32)
+    def bwd_scratch(self, rows, n_slots):
+        return self.zeros((ops.shard_bwd_scratch_floats(rows, self.n_dense, n_slots),), torch.float32)
 
     # step pieces: one launch each ---------------------------------------------------------------
     def route(self, ids, send):
@@ -174,7 +174,7 @@ class ShardedFactorizationMachine(object):
         self.n_total = be.zeros((1,), i32)
         self.partial, self.partials_in = be.zeros((N, B, D + 2), f32), be.zeros((N, B, D + 2), f32)
         self.X, self.X_all = be.zeros((B, self.ld), f32), be.zeros((N * B, self.ld), f32)
-        self.scratch = be.dense_scratch(N * B)
+        self.scratch = be.bwd_scratch(N * B, N * B * T)
         self.loss = be.zeros((1,), f32)
         self._B = B
 

@@ -35,7 +35,7 @@ class NumpyBackend(object):
     def zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype)
 
-    def dense_scratch(self, rows):
+    def bwd_scratch(self, rows, n_slots):
         return torch.zeros((1,), dtype=torch.float32)
 
     def first_local(self, t):
