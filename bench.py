@@ -90,6 +90,34 @@ def time_stage(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def sharded_stage_report(m, batch, reps, idx_bits):
+    """Per-launch device time and ALGORITHMIC bytes of one rank's share of a sharded FM step, timed on
+    the buffers the last step left behind (no collectives inside: they are reported by the step time)."""
+    ids, dense, labels = batch
+    B, T = ids.shape
+    N, D, nd = m.world, m.dim, m.n_dense
+    ib = idx_bits // 8
+    n = int(m.n_total.item())
+    U = int(torch.unique(m.sorted_rows[:n]).numel())
+    blk = m.send.shape[1]
+    n_state = {'sgd': 0, 'adagrad_rowwise': 1.0 / D, 'adam_tf': 2}[m.opt]
+    n_state_w1 = {'sgd': 0, 'adagrad_rowwise': 1, 'adam_tf': 2}[m.opt]
+    stages = []
+
+    def add(name, fn, nbytes):
+        ms = time_stage(fn, reps)
+        stages.append(dict(name=name, ms=round(ms, 5), kernels=1, alg_bytes=int(nbytes), gbs=round(nbytes / ms / 1e6, 1)))
+
+    add('launch 1: route (ids -> per-owner slot blocks)', lambda: m.phase_route(ids), B * T * ib + N * blk * 4)
+    add('launch 2: owner forward + per-table LDS sort', lambda: m.phase_owner_forward(),
+        N * blk * 4 + n * (D * 4 + 4) + N * B * (D + 2) * 4 + n * 8)
+    add('launch 3: combine (owners\' partials -> logit, loss, X rows)', lambda: m.phase_combine(dense, labels),
+        N * B * (D + 2) * 4 + B * nd * 4 + B * m.ld * 4)
+    add('launch 4: owner sparse update (segmented sum + fused %s) + dense side' % m.opt, lambda: m.phase_update(),
+        n * (8 + (D + 1) * 4) + U * D * 4 * 2 * (1 + n_state) + U * 4 * 2 * (1 + n_state_w1) + N * B * (nd + 2) * 4)
+    return stages, n, U
+
+
 def stage_report(fm, batch, reps, idx_bits):
     """Per-stage device time and ALGORITHMIC bytes of one FM step at this batch."""
     from recommendation_amd import ops
@@ -347,7 +375,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     sharded = world > 1 or args.force_sharded
+    saved_stdout = None
     if sharded:
+        # RCCL prints a version banner on stdout when its communicator is created; stdout must carry
+        # the one JSON line only, so everything before it goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         if world == 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29577')
@@ -424,9 +458,28 @@ def main():
         result['embedding_hbm_gbs'] = round(sum(s['alg_bytes'] for s in emb) / sum(s['ms'] for s in emb) / 1e6, 1)
         if not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args, rows, model, batches)
-    if rank == 0:
-        print(json.dumps(result))
+    if sharded and rank == 0:
+        stages, n_owner, U = sharded_stage_report(model, batches[0], args.stage_reps, args.idx_bits)
+        dom = stages[3]
+        result['stages'] = stages
+        result['entries_at_this_owner'] = n_owner
+        result['unique_rows_per_step'] = U
+        coll = ops.shard_block_ints(B, len(rows)) * 4 * world, B * (args.dim + 2) * 4 * world, B * model.ld * 4
+        result['collectives'] = {'all_to_all_rows_bytes_per_rank': coll[0], 'all_to_all_partials_bytes_per_rank': coll[1],
+                                 'all_gather_rows_bytes_per_rank': coll[2]}
+        result['roofline'] = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS,
+                              'unit': 'GB/s', 'frac': round(dom['gbs'] / HBM_PEAK_GBS, 4), 'traffic': None,
+                              'alg_bytes_per_launch': dom['alg_bytes'], 'ms_per_launch': dom['ms']}
     if sharded:
+        torch.distributed.barrier()       # the other ranks wait for rank 0's stage timings before tearing down
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if sharded:
+        os.dup2(2, 1)                      # teardown messages, if any, do not follow the JSON line on stdout
         torch.distributed.destroy_process_group()
 
 

@@ -14,7 +14,7 @@ print("| kernel | calls | avg us | min us | max us | total % |")
 print("|---|---|---|---|---|---|")
 for r in rows:
     n = r['Name']
-    if 'at::native' in n or 'rocclr' in n or 'hiprand' in n.lower():
+    if 'at::native' in n or 'rocclr' in n or 'hiprand' in n.lower() or 'rocprim' in n:
         continue
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
     n = re.sub(r'\(.*', '', n)
