@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument('--cpu-steps', type=int, default=20)
     ap.add_argument('--stage-reps', type=int, default=50)
     ap.add_argument('--no-graph', action='store_true', help='launch the step eagerly instead of replaying a HIP graph')
+    ap.add_argument('--prefetch', action='store_true',
+                    help='sharded path: route and exchange the ids of the next batch on a side stream beside this step\'s update '
+                         '(measured slower at world size 1: the extra stream hops cost more than the exchange they hide)')
     ap.add_argument('--force-sharded', action='store_true',
                     help='use the row-wise sharded model and its collectives even with one rank (rehearsal of the N > 1 path)')
     ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer'],
@@ -411,6 +414,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if sharded and args.prefetch:   # the next batch's ids are routed and exchanged beside this step's update
+            kw = {'next_ids': batches[(i + 1) % len(batches)][0]}
         model.train_step(*batches[i % len(batches)], **kw)
     barrier()
     dt = time.perf_counter() - t0

@@ -142,6 +142,7 @@ class ShardedFactorizationMachine(object):
         self.err = getattr(self.be, 'err', None)
         self._B = None
         self.loss = None
+        self._prefetched, self._side = None, None
 
     # -- parameters ---------------------------------------------------------------------------
     @property
@@ -205,14 +206,40 @@ class ShardedFactorizationMachine(object):
                        self.beta1, self.beta2, self.eps, self.sched, self.scratch, self.loss)
 
     # -- one step over torch.distributed --------------------------------------------------------
-    def train_step(self, ids, dense, labels, check_ids=False):
-        c = self.comm
+    def _route_and_send(self, ids):
         self.phase_route(ids)
-        c.all_to_all(self.recv, self.send)                 # A
+        self.comm.all_to_all(self.recv, self.send)         # A
+
+    def train_step(self, ids, dense, labels, check_ids=False, next_ids=None):
+        """One synchronous step.  ``next_ids``: the ids of the batch the NEXT call will be given;
+        their routing and exchange A depend on no model state, so they are issued on a side stream
+        as soon as this step's owner forward has consumed the receive buffer and run beside this
+        step's update instead of in front of the next step."""
+        c = self.comm
+        cuda = self.device.type == 'cuda'
+        routed = None
+        if self._prefetched is not None:
+            routed, arrived = self._prefetched
+            torch.cuda.current_stream(self.device).wait_event(arrived)   # the prefetched exchange A is done
+            self._prefetched = None
+        if routed != (ids.data_ptr(), ids.shape[0]):
+            self._route_and_send(ids)
         self.phase_owner_forward()
+        if cuda and next_ids is not None:
+            if self._side is None:
+                self._side = torch.cuda.Stream(self.device)
+                self._consumed, self._arrived = torch.cuda.Event(), torch.cuda.Event()
+            self._consumed.record()                         # recv and send are free again after this point
         c.all_to_all(self.partials_in, self.partial)       # B
         self.phase_combine(dense, labels)
         c.all_gather(self.X_all, self.X)                   # C
+        if cuda and next_ids is not None:
+            # issued after C so that every rank enqueues its collectives in the same order
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(self._consumed)
+                self._route_and_send(next_ids)
+                self._arrived.record()
+            self._prefetched = ((next_ids.data_ptr(), next_ids.shape[0]), self._arrived)
         self.phase_update()
         if check_ids and hasattr(self.be, 'check'):
             self.be.check()

@@ -210,3 +210,36 @@ def test_owner_forward_and_sort_bit_exact(dev, case):
                              0.999, err)
     with pytest.raises(ops.InvalidArgumentError):
         ops.check_error_word(err, "slots")
+
+
+def test_train_step_over_rccl_world1_with_and_without_prefetch(dev):
+    """The real train_step (torch.distributed, backend nccl = RCCL, one rank): routing the next
+    batch on the side stream must not change a bit, and both must match the lockstep driver."""
+    import os
+    import torch.distributed as dist
+    from recommendation_amd.sharded import ShardedFactorizationMachine, lockstep_train_step
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+    try:
+        rows = [1460, 583, 30001, 305, 24, 3, 10, 4]
+        ref = ofm.State(rows, 16, 13, seed=5, opt="adam_tf")
+        models = [ShardedFactorizationMachine(rows, 16, 13, device=dev, opt="adam_tf", lr=1e-2) for _ in range(2)]
+        lock = ShardedFactorizationMachine(rows, 16, 13, device=dev, opt="adam_tf", lr=1e-2, rank=0, world=1)
+        for m in models + [lock]:
+            m.load_state(ref)
+        batches = [tuple(torch.from_numpy(a).to(dev) for a in ofm.synthetic_batch(1024, rows, 13, seed=s, dist='zipf'))
+                   for s in range(4)]
+        for i, b in enumerate(batches):
+            nxt = batches[i + 1][0] if i + 1 < len(batches) else None
+            l0 = models[0].train_step(*b)
+            l1 = models[1].train_step(*b, next_ids=nxt)
+            l2 = lockstep_train_step([lock], [b])
+            assert torch.equal(l0, l1) and torch.equal(l0, l2)
+        torch.cuda.synchronize()
+        for m in models[1:] + [lock]:
+            assert torch.equal(m.be.table.rec, models[0].be.table.rec)
+            assert torch.equal(m.dp, models[0].dp)
+            m.be.check()
+    finally:
+        dist.destroy_process_group()
