@@ -115,9 +115,9 @@ def sharded_stage_report(m, batch, reps, idx_bits):
     add('launch 2: owner forward + per-table LDS sort', lambda: m.phase_owner_forward(),
         N * blk * 4 + n * (D * 4 + 4) + N * B * (D + 2) * 4 + n * 8)
     add('launch 3: combine (owners\' partials -> logit, loss, X rows)', lambda: m.phase_combine(dense, labels),
-        N * B * (D + 2) * 4 + B * nd * 4 + B * m.ld * 4)
+        N * B * (D + 2) * 4 + B * nd * 4 + m.rs * m.ld * 4)
     add('launch 4: owner sparse update (segmented sum + fused %s) + dense side' % m.opt, lambda: m.phase_update(),
-        n * (8 + (D + 1) * 4) + U * D * 4 * 2 * (1 + n_state) + U * 4 * 2 * (1 + n_state_w1) + N * B * (nd + 2) * 4)
+        n * (8 + (D + 1) * 4) + U * D * 4 * 2 * (1 + n_state) + U * 4 * 2 * (1 + n_state_w1) + N * (m.rs - B) * m.ld * 4)
     return stages, n, U
 
 
@@ -469,7 +469,7 @@ def main():
         result['stages'] = stages
         result['entries_at_this_owner'] = n_owner
         result['unique_rows_per_step'] = U
-        coll = ops.shard_block_ints(B, len(rows)) * 4 * world, B * (args.dim + 2) * 4 * world, B * model.ld * 4
+        coll = ops.shard_block_ints(B, len(rows)) * 4 * world, B * (args.dim + 2) * 4 * world, model.rs * model.ld * 4
         result['collectives'] = {'all_to_all_rows_bytes_per_rank': coll[0], 'all_to_all_partials_bytes_per_rank': coll[1],
                                  'all_gather_rows_bytes_per_rank': coll[2]}
         result['roofline'] = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS,

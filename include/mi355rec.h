@@ -335,8 +335,8 @@ int mi_shard_route(const int64_t* table_offsets, int T, const void* ids, int idx
 /* Owner, ONE launch: recv[N][blk] = the blocks received from every rank.  Writes
  *   partial[N][B][dim+2]   { sum v (dim), sum |v|^2, sum w1 } per (source rank, sample)
  *   sorted_rows[n]         the local rows of all valid slots, ascending (tables lie in row order)
- *   perm[n]                s*B + b of every sorted entry (the row of X_all the backward reads);
- *                          stable: equal rows keep (s, b) order
+ *   perm[n]                s*row_stride + b of every sorted entry (the row of X_all the backward
+ *                          reads; row_stride >= B); stable: equal rows keep (s, b) order
  *   n_total[0]             n <= N*B*T (size sorted_rows / perm for that)
  * and, when sched != NULL, advances the Adam schedule (see mi_adam_schedule_step).  sorted_rows,
  * perm and n_total may all be NULL (forward only).  Any id skew is sorted correctly: a table with
@@ -344,31 +344,36 @@ int mi_shard_route(const int64_t* table_offsets, int T, const void* ids, int idx
  * n_ranks * B < 2^24, T <= 64. */
 int mi_shard_owner_fwd_sort(const mi_fm_table* tab, int64_t local_rows, const int64_t* table_offsets,
                             int T, int rank, int n_ranks, const int32_t* recv, int64_t B,
-                            float* partial, uint32_t* sorted_rows, int32_t* perm, int32_t* n_total,
+                            int64_t row_stride, float* partial, uint32_t* sorted_rows, int32_t* perm, int32_t* n_total,
                             float* sched, float lr, float beta1, float beta2, int32_t* err,
                             void* stream);
 
 /* Requester: partials[N][B][dim+2] (one slab per owner, summed in rank order) + dense part +
  * bias -> one row per sample of what the other ranks need,
  *   X[b] = [ S (dim) | g = (sigmoid(logit)-y)*gscale | BCE loss row | dense[b] (n_dense) | 0.. ]
- * with ld floats per row (ld % 4 == 0, ld >= dim+2+n_dense).  logit may be NULL. */
+ * with ld floats per row (ld % 4 == 0, ld >= dim+2+n_dense).  logit may be NULL.  part_out (may be
+ * NULL): mi_shard_dense_part_floats(B, dim, n_dense) floats, one partial per workgroup of this
+ * launch of the dense-side sums over its samples (sum g*dense[.][j], sum g, sum loss); placed right
+ * behind the B rows of X it travels with them in the all-gather. */
+int64_t mi_shard_dense_part_floats(int64_t B, int dim, int n_dense);
 int mi_fm_combine(const float* partials, int n_ranks, int64_t B, int dim, const float* dense,
                   int n_dense, const float* wd, const float* bias, const float* labels,
-                  float gscale, float* logit, float* X, int ld, void* stream);
+                  float gscale, float* logit, float* X, int ld, float* part_out, void* stream);
 
 /* Owner + replica, ONE launch after the all-gather: the sparse backward with the fused optimizer
  * over sorted_rows / perm / n_total as mi_shard_owner_fwd_sort wrote them (n_slots = their capacity,
- * which sizes the launch), reading g and S
- * from X_all[rows][ld]; and the dense side over ALL rows of X_all: every replica computes the
- * dense-side gradients of all N*B samples itself, in the same order on every rank, so replicas
- * stay bit-identical without an all-reduce; TensorFlow-form Adam on dp[n_dense+1] = {wd, bias},
- * loss_out[0] = mean of the loss column.  scratch: mi_shard_bwd_scratch_floats(rows, n_dense,
- * n_slots) floats, zeroed once by the caller. */
-int64_t mi_shard_bwd_scratch_floats(int64_t rows, int n_dense, int64_t n_slots);
+ * which sizes the launch), reading g and S from the gathered matrix X_all (rank s owns rows
+ * [s*row_stride, (s+1)*row_stride): B sample rows, then the partials of its combine launch); and
+ * the dense side: one workgroup adds the partials of all ranks in a fixed order - the same bits on
+ * every replica, no all-reduce - applies TensorFlow-form Adam to dp[n_dense+1] = {wd, bias} and
+ * writes loss_out[0] = mean loss over the n_ranks*B samples.  scratch:
+ * mi_shard_bwd_scratch_floats(n_slots) floats, zeroed once by the caller. */
+int64_t mi_shard_bwd_scratch_floats(int64_t n_slots);
 int mi_shard_owner_bwd_dense(const mi_fm_table* tab, int64_t local_rows, const uint32_t* sorted_rows,
-                             const int32_t* perm, const int32_t* n_total, int64_t n_slots, const float* X, int ld,
-                             int64_t rows, int opt, float lr, const float* lr_dev, float beta1,
-                             float beta2, float eps, int n_dense, float* dp, float* dm, float* dv,
+                             const int32_t* perm, const int32_t* n_total, int64_t n_slots,
+                             const float* X_all, int ld, int n_ranks, int64_t B, int64_t row_stride,
+                             int opt, float lr, const float* lr_dev, float beta1, float beta2,
+                             float eps, int n_dense, float* dp, float* dm, float* dv,
                              float dense_lr_t, const float* dense_lr_dev, float* scratch,
                              float* loss_out, void* stream);
 

@@ -101,11 +101,12 @@ _SIGNATURES = {
     'mi_parse_records': (c_int, [c_char_p, c_int64, c_int, c_int, c_int64, P, P, POINTER(c_int64), POINTER(c_int64)]),
     'mi_shard_block_ints': (c_int64, [c_int64, c_int]),
     'mi_shard_route': (c_int, [P, c_int, P, c_int, c_int64, c_int, P, P, P]),
-    'mi_shard_owner_fwd_sort': (c_int, [POINTER(FmTable), c_int64, P, c_int, c_int, c_int, P, c_int64, P, P, P, P, P,
+    'mi_shard_owner_fwd_sort': (c_int, [POINTER(FmTable), c_int64, P, c_int, c_int, c_int, P, c_int64, c_int64, P, P, P, P, P,
                                         c_float, c_float, c_float, P, P]),
-    'mi_fm_combine': (c_int, [P, c_int, c_int64, c_int, P, c_int, P, P, P, c_float, P, P, c_int, P]),
-    'mi_shard_bwd_scratch_floats': (c_int64, [c_int64, c_int, c_int64]),
-    'mi_shard_owner_bwd_dense': (c_int, [POINTER(FmTable), c_int64, P, P, P, c_int64, P, c_int, c_int64, c_int, c_float,
+    'mi_fm_combine': (c_int, [P, c_int, c_int64, c_int, P, c_int, P, P, P, c_float, P, P, c_int, P, P]),
+    'mi_shard_dense_part_floats': (c_int64, [c_int64, c_int, c_int]),
+    'mi_shard_bwd_scratch_floats': (c_int64, [c_int64]),
+    'mi_shard_owner_bwd_dense': (c_int, [POINTER(FmTable), c_int64, P, P, P, c_int64, P, c_int, c_int, c_int64, c_int64, c_int, c_float,
                                          P, c_float, c_float, c_float, c_int, P, P, P, c_float, P, P, P, P]),
     'mi_fm_dense_step_rows': (c_int, [P, c_int, c_int, c_int, c_int64, P, P, P, c_float, P, c_float, c_float,
                                       c_float, P, P]),

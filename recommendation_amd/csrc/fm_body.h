@@ -176,18 +176,15 @@ __device__ __forceinline__ void fm_dense_body(const FmDenseArgs& a, int j, float
   }
 }
 
-// The dense side over the rows of a gathered sample matrix X[rows][ld] =
-// [ S (dim) | g | loss | dense (n_dense) | pad ], split over `chunks` workgroups: each reduces its
-// rows for all n_dense+2 columns at once (CT threads across a row, FM_DENSE_THREADS/CT rows in
-// flight; fixed order), leaves a partial in part[chunk][CT], and the workgroup that finishes last
-// adds the partials in chunk order and applies TensorFlow-form Adam / writes the mean loss.  The
-// result depends only on rows and chunks.  *ticket must be 0 before the first call; it is left 0.
-struct FmDenseRowsArgs {
-  const float* X;
-  int64_t ld, rows;
-  int dim, n_dense, chunks, ct;  // ct: power of two >= n_dense + 2, <= FM_DENSE_THREADS
-  float* part;
-  int* ticket;
+// The dense side of a sharded step.  Every rank's combine launch left, behind its B sample rows of
+// the gathered matrix, one partial per workgroup: part[k][ct] = that workgroup's sums of
+// g*dense[.][j] (j < n_dense), g and loss.  ONE workgroup adds the n_ranks*n_blocks partials in a
+// fixed order (thread (r, j) takes partials r, r+rl, ...; then a tree over r) and applies
+// TensorFlow-form Adam to dp = {wd, bias} / writes the mean loss: the same bits on every replica.
+struct FmDenseFinalArgs {
+  const float* X;    // gathered matrix: rank s owns rows [s*row_stride, (s+1)*row_stride)
+  int64_t ld, row_stride, B;
+  int n_ranks, n_blocks, ct, n_dense;
   float* dp;
   float* dm;
   float* dv;
@@ -197,78 +194,44 @@ struct FmDenseRowsArgs {
   float* loss_out;
 };
 
-__device__ __forceinline__ void fm_dense_rows_body(const FmDenseRowsArgs& a, int chunk, float* sh) {
+__device__ __forceinline__ void fm_dense_final_body(const FmDenseFinalArgs& a, float* sh) {
   constexpr int NT = FM_DENSE_THREADS;
-  __shared__ int last;
   const int ct = a.ct, rl = NT / ct;
   const int j = threadIdx.x % ct, rr = threadIdx.x / ct;
-  const int64_t per = (a.rows + a.chunks - 1) / a.chunks;
-  const int64_t lo = chunk * per, hi = lo + per < a.rows ? lo + per : a.rows;
-  const int col = j < a.n_dense ? a.dim + 2 + j : (j == a.n_dense ? a.dim : a.dim + 1);
-  float acc = 0.f;
-  if (j < a.n_dense + 2) {
-    // four rows in flight per thread; their terms are added in row order
-    for (int64_t r = lo + rr; r < hi; r += 4 * rl) {
-      float g[4], v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t ru = r + u * rl;
-        const float* x = a.X + (ru < hi ? ru : r) * a.ld;
-        g[u] = x[a.dim];
-        v[u] = x[col];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (r + u * rl < hi) acc = j < a.n_dense ? fmaf(g[u], v[u], acc) : acc + v[u];
-    }
-  }
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = rl / 2; s > 0; s >>= 1) {
-    if (rr < s) sh[threadIdx.x] += sh[threadIdx.x + s * ct];
-    __syncthreads();
-  }
-  if (rr == 0) a.part[(size_t) chunk * ct + j] = sh[j];
-  __threadfence();  // the partial is visible device-wide before the ticket is taken
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(a.ticket, 1) == a.chunks - 1 ? 1 : 0;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  // same shape as above over the partials: thread (rr, j) adds chunks rr, rr+rl, ... (loads issued in
-  // batches of eight), then the tree over rr
+  const int total = a.n_ranks * a.n_blocks;
   float tot = 0.f;
-  for (int c0 = rr; c0 < a.chunks; c0 += 8 * rl) {
+  for (int i0 = rr; i0 < total; i0 += 8 * rl) {
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int c = c0 + u * rl;
-      v[u] = c < a.chunks ? __builtin_nontemporal_load(a.part + (size_t) c * ct + j) : 0.f;
+      const int i = i0 + u * rl;
+      v[u] = 0.f;
+      if (i < total) {
+        const int s = i / a.n_blocks, k = i - s * a.n_blocks;
+        v[u] = a.X[(s * a.row_stride + a.B) * a.ld + (int64_t) k * ct + j];
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) tot += v[u];
   }
-  __syncthreads();
   sh[threadIdx.x] = tot;
   __syncthreads();
   for (int s = rl / 2; s > 0; s >>= 1) {
     if (rr < s) sh[threadIdx.x] += sh[threadIdx.x + s * ct];
     __syncthreads();
   }
-  if ((int) threadIdx.x < a.n_dense + 2) {
-    const int k = threadIdx.x;
-    tot = sh[k];
-    if (k == a.n_dense + 1) {
-      a.loss_out[0] = tot / (float) a.rows;
-    } else {
-      const float mi = a.dm[k] + (tot - a.dm[k]) * (1.0f - a.b1);
-      const float vi = a.dv[k] + (tot * tot - a.dv[k]) * (1.0f - a.b2);
-      a.dm[k] = mi;
-      a.dv[k] = vi;
-      a.dp[k] -= (mi * (a.lr_dev ? a.lr_dev[0] : a.lr_t)) / (sqrtf(vi) + a.eps);
-    }
+  if ((int) threadIdx.x >= a.n_dense + 2) return;
+  const int k = threadIdx.x;
+  tot = sh[k];
+  if (k == a.n_dense + 1) {
+    a.loss_out[0] = tot / (float) (a.B * a.n_ranks);
+    return;
   }
-  if (threadIdx.x == 0) atomicExch(a.ticket, 0);
+  const float mi = a.dm[k] + (tot - a.dm[k]) * (1.0f - a.b1);
+  const float vi = a.dv[k] + (tot * tot - a.dv[k]) * (1.0f - a.b2);
+  a.dm[k] = mi;
+  a.dv[k] = vi;
+  a.dp[k] -= (mi * (a.lr_dev ? a.lr_dev[0] : a.lr_t)) / (sqrtf(vi) + a.eps);
 }
 
 // sched = {alpha_t, beta1_power, beta2_power}: TensorFlow keeps the two powers as fp32 variables

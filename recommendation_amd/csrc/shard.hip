@@ -81,6 +81,7 @@ struct OwnerArgs {
   const int32_t* recv;  // [N] blocks of `stride` ints: cnt[n_chunks][T], then slot[T][B]
   int64_t stride;
   int T, B, N, rank, n_chunks;
+  int row_stride;  // rows of the gathered sample matrix per source rank (>= B): entry (s, b) is row s*row_stride + b
   __device__ __forceinline__ const int32_t* cnt(int s) const { return recv + (size_t) s * stride; }
   __device__ __forceinline__ const int32_t* slots(int s) const { return recv + (size_t) s * stride + (size_t) n_chunks * T; }
   float* partial;
@@ -179,6 +180,7 @@ struct OwnerStream {
   const int32_t* slots;  // table t's slots of source 0
   int64_t stride;        // ints between consecutive sources
   int B, NC, n_pairs;    // samples per source, 64-slot chunks per source, (source, chunk) pairs = N*NC
+  int RS;                // payload of entry (s, b) = s*RS + b
   int64_t lo;
   uint32_t rows;
   __device__ __forceinline__ uint32_t to_key(int32_t v) const {
@@ -213,7 +215,7 @@ struct OsFrame {
 // Wave w walks its contiguous run of (source, chunk) pairs, OS_FLIGHT chunks in flight (what these
 // passes cost is dependent round trips to memory, so few, wide rounds); f(key, e) is called by all
 // lanes of the wave together for every chunk (key = OS_INVALID past a source's last sample),
-// e = s*B + b being the entry's place in stream order.
+// e = s*RS + b being the entry's payload (ascending in stream order).
 constexpr int OS_FLIGHT = 32;
 template <class F>
 __device__ __forceinline__ void os_stream(const OwnerStream& S, F&& f) {
@@ -233,7 +235,7 @@ __device__ __forceinline__ void os_stream(const OwnerStream& S, F&& f) {
     }
 #pragma unroll
     for (int u = 0; u < OS_FLIGHT; ++u) {
-      if (p0 + u < end) f(S.to_key(v[u]), it.s * S.B + it.ch * 64 + lane);
+      if (p0 + u < end) f(S.to_key(v[u]), it.s * S.RS + it.ch * 64 + lane);
       it.advance(1, S.NC);
     }
   }
@@ -470,7 +472,7 @@ __device__ __forceinline__ void owner_sort_body(TsLds& L, uint32_t (*lvl)[TS_RAD
   OwnerStream S;
   S.slots = a.slots(0) + (size_t) t * a.B;
   S.stride = a.stride;
-  S.B = a.B; S.NC = NC; S.n_pairs = N * NC;
+  S.B = a.B; S.NC = NC; S.n_pairs = N * NC; S.RS = a.row_stride;
   S.lo = first_local(a.toffs, t, a.rank, N);
   S.rows = (uint32_t) (first_local(a.toffs, t + 1, a.rank, N) - S.lo);
   int bits = 0;
@@ -610,7 +612,7 @@ __device__ __forceinline__ void owner_sort_body(TsLds& L, uint32_t (*lvl)[TS_RAD
 #pragma unroll
               for (int k = 0; k < 4; ++k) before += (uint32_t) __popcll(__ballot(x[k] >= 0) & lt);
               uint32_t d = cbase[p] + before;
-              const uint32_t e0 = (uint32_t) (it.s * a.B + it.ch * 256 + lane * 4);
+              const uint32_t e0 = (uint32_t) (it.s * a.row_stride + it.ch * 256 + lane * 4);
 #pragma unroll
               for (int k = 0; k < 4; ++k)
                 if (x[k] >= 0) put(d++, min((uint32_t) ((int64_t) x[k] - S.lo), kmax), e0 + k);
@@ -639,7 +641,7 @@ __device__ __forceinline__ void owner_sort_body(TsLds& L, uint32_t (*lvl)[TS_RAD
             const unsigned long long bal = __ballot(ok);
             if (ok)
               put(cbase[p] + (uint32_t) __popcll(bal & lt), min((uint32_t) ((int64_t) v[u] - S.lo), kmax),
-                  (uint32_t) (it.s * a.B + it.ch * 64 + lane));
+                  (uint32_t) (it.s * a.row_stride + it.ch * 64 + lane));
           }
           it.advance(TS_WAVES, UPS);
         }
@@ -742,13 +744,18 @@ __global__ __launch_bounds__(256) void fm_combine_kernel(const float* __restrict
                                                         const float* __restrict__ dense, int n_dense,
                                                         const float* __restrict__ wd, const float* __restrict__ bias,
                                                         const float* __restrict__ labels, float gscale,
-                                                        float* __restrict__ logit, float* __restrict__ X, int ld) {
+                                                        float* __restrict__ logit, float* __restrict__ X, int ld,
+                                                        float* __restrict__ part_out, int ct) {
   constexpr int CH = DIM / 4;
-  const int b = blockIdx.x * (256 / CH) + threadIdx.x / CH;
-  if (b >= B) return;
+  constexpr int SPB = 256 / CH;  // samples per workgroup
+  __shared__ float sh_g[SPB], sh_l[SPB], sh_red[256];
+  const int bl = threadIdx.x / CH;
+  const int b = blockIdx.x * SPB + bl;
   const int c = threadIdx.x % CH;
+  const bool live = b < B;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   float q = 0.f, lin = 0.f;
+  if (live) {
   for (int r = 0; r < N; ++r) {
     const float* p = partials + ((size_t) r * B + b) * (DIM + 2);
     s.x += p[c * 4 + 0]; s.y += p[c * 4 + 1]; s.z += p[c * 4 + 2]; s.w += p[c * 4 + 3];
@@ -781,7 +788,30 @@ __global__ __launch_bounds__(256) void fm_combine_kernel(const float* __restrict
     }
     x[DIM] = gb;
     x[DIM + 1] = loss;
+    sh_g[bl] = gb;
+    sh_l[bl] = loss;
   }
+  } else if (c == 0) {
+    sh_g[bl] = 0.f;
+    sh_l[bl] = 0.f;
+  }
+  if (!part_out) return;  // uniform
+  // This workgroup's share of the dense-side sums, columns j < n_dense: sum g*dense[.][j]; then
+  // sum g; then sum loss.  Thread (r, j) adds samples r, r+rl, ... in order, then a tree over r.
+  __syncthreads();
+  const int rl = 256 / ct, j = threadIdx.x % ct, r0 = threadIdx.x / ct;
+  const int b0 = blockIdx.x * SPB;
+  float acc = 0.f;
+  if (j < n_dense + 2)
+    for (int i = r0; i < SPB && b0 + i < B; i += rl)
+      acc = j < n_dense ? fmaf(sh_g[i], dense[(size_t) (b0 + i) * n_dense + j], acc) : acc + (j == n_dense ? sh_g[i] : sh_l[i]);
+  sh_red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = rl / 2; st > 0; st >>= 1) {
+    if (r0 < st) sh_red[threadIdx.x] += sh_red[threadIdx.x + st * ct];
+    __syncthreads();
+  }
+  if (r0 == 0) part_out[(size_t) blockIdx.x * ct + j] = sh_red[j];
 }
 
 }  // namespace
@@ -808,7 +838,8 @@ extern "C" int mi_shard_route(const int64_t* table_offsets, int T, const void* i
 }
 
 extern "C" int mi_shard_owner_fwd_sort(const mi_fm_table* tab, int64_t local_rows, const int64_t* table_offsets, int T,
-                                       int rank, int n_ranks, const int32_t* recv, int64_t B, float* partial,
+                                       int rank, int n_ranks, const int32_t* recv, int64_t B, int64_t row_stride,
+                                       float* partial,
                                        uint32_t* sorted_rows, int32_t* perm, int32_t* n_total, float* sched,
                                        float lr, float beta1, float beta2, int32_t* err, void* stream) {
   const char* who = "mi_shard_owner_fwd_sort";
@@ -822,8 +853,9 @@ extern "C" int mi_shard_owner_fwd_sort(const mi_fm_table* tab, int64_t local_row
   MI_REQUIRE(n_ranks >= 1 && n_ranks <= MAX_RANKS && rank >= 0 && rank < n_ranks && T >= 1 && B >= 1 &&
                  B < ((int64_t) 1 << 24) / n_ranks && (int64_t) n_ranks * B * T < ((int64_t) 1 << 31),
              "%s: bad rank/n_ranks/B/T (n_ranks*B < 2^24)", who);
+  MI_REQUIRE(row_stride >= B && (int64_t) n_ranks * row_stride < ((int64_t) 1 << 31), "%s: row_stride must be >= B", who);
   OwnerArgs a{*tab, table_offsets, recv, mi_shard_block_ints(B, T), T, (int) B, n_ranks, rank,
-              (int) mi_cdiv(B, ROUTE_SAMPLES), partial, err};
+              (int) mi_cdiv(B, ROUTE_SAMPLES), (int) row_stride, partial, err};
   hipStream_t s = (hipStream_t) stream;
   const int64_t bags = (int64_t) n_ranks * B;
   const size_t lds = (size_t) (T + 1) * sizeof(int32_t);
@@ -848,9 +880,20 @@ extern "C" int mi_shard_owner_fwd_sort(const mi_fm_table* tab, int64_t local_row
   return MI_OK;
 }
 
+static int dense_ct(int n_dense) {
+  int ct = 1;
+  while (ct < n_dense + 2) ct <<= 1;
+  return ct;
+}
+
+extern "C" int64_t mi_shard_dense_part_floats(int64_t B, int dim, int n_dense) {
+  return dim >= 4 ? mi_cdiv(B, 256 / (dim / 4)) * dense_ct(n_dense) : 0;
+}
+
 extern "C" int mi_fm_combine(const float* partials, int n_ranks, int64_t B, int dim, const float* dense,
                              int n_dense, const float* wd, const float* bias, const float* labels, float gscale,
-                             float* logit, float* X, int ld, void* stream) {
+                             float* logit, float* X, int ld, float* part_out, void* stream) {
+  MI_REQUIRE(n_dense + 2 <= 256, "mi_fm_combine: at most 254 dense features");
   MI_REQUIRE(partials && X && n_ranks >= 1 && B >= 1, "mi_fm_combine: bad arguments");
   MI_REQUIRE(n_dense == 0 || (dense && wd), "mi_fm_combine: dense features need dense and wd");
   MI_REQUIRE(ld >= dim + 2 + n_dense && ld % 4 == 0 && ((uintptr_t) X & 15) == 0,
@@ -859,7 +902,8 @@ extern "C" int mi_fm_combine(const float* partials, int n_ranks, int64_t B, int 
 #define CB_CASE(D)                                                                                                 \
   case D:                                                                                                          \
     hipLaunchKernelGGL(fm_combine_kernel<D>, dim3((unsigned) mi_cdiv(B, 256 / (D / 4))), dim3(256), 0, s, partials, \
-                       n_ranks, (int) B, dense, n_dense, wd, bias, labels, gscale, logit, X, ld);                   \
+                       n_ranks, (int) B, dense, n_dense, wd, bias, labels, gscale, logit, X, ld, part_out,          \
+                       dense_ct(n_dense));                                                                          \
     break;
   switch (dim) {
     CB_CASE(4) CB_CASE(8) CB_CASE(16) CB_CASE(32) CB_CASE(64) CB_CASE(128)

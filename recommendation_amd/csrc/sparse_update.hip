@@ -575,10 +575,10 @@ struct FmDenseExtra {
   FmDenseArgs a;
   __device__ __forceinline__ void run(int j, float* sh) const { fm_dense_body(a, j, sh); }
 };
-struct FmDenseRowsExtra {
-  int blocks;
-  FmDenseRowsArgs a;
-  __device__ __forceinline__ void run(int j, float* sh) const { fm_dense_rows_body(a, j, sh); }
+struct FmDenseFinalExtra {
+  int blocks;  // 1
+  FmDenseFinalArgs a;
+  __device__ __forceinline__ void run(int, float* sh) const { fm_dense_final_body(a, sh); }
 };
 static_assert(FM_DENSE_THREADS == UBLOCK, "the dense side runs in workgroups of the sparse update's size");
 
@@ -1045,48 +1045,40 @@ extern "C" int mi_fm_bwd_apply(const mi_bwd_plan* plan, const mi_fm_table* tab, 
                            beta2, eps, stream, NoExtra{0});
 }
 
-static int64_t dense_rows_chunks(int64_t rows) { return rows < 1 ? 1 : (rows + 255) / 256 > 512 ? 512 : (rows + 255) / 256; }
-
-extern "C" int64_t mi_shard_bwd_scratch_floats(int64_t rows, int n_dense, int64_t n_slots) {
-  int ct = 1;
-  while (ct < n_dense + 2) ct <<= 1;
-  // the sparse update's long-run scratch (n_slots + 2 words), then the dense side's partials and ticket
-  return (n_slots + 2) + dense_rows_chunks(rows) * ct + 1;
-}
+extern "C" int64_t mi_shard_bwd_scratch_floats(int64_t n_slots) { return n_slots + 2; }
 
 extern "C" int mi_shard_owner_bwd_dense(const mi_fm_table* tab, int64_t local_rows, const uint32_t* sorted_rows,
                                         const int32_t* perm, const int32_t* n_total, int64_t n_slots, const float* X,
-                                        int ld, int64_t rows,
-                                        int opt, float lr, const float* lr_dev, float beta1, float beta2, float eps,
-                                        int n_dense, float* dp, float* dm, float* dv, float dense_lr_t,
-                                        const float* dense_lr_dev, float* scratch, float* loss_out, void* stream) {
+                                        int ld, int n_ranks, int64_t B, int64_t row_stride, int opt, float lr,
+                                        const float* lr_dev, float beta1, float beta2, float eps, int n_dense,
+                                        float* dp, float* dm, float* dv, float dense_lr_t, const float* dense_lr_dev,
+                                        float* scratch, float* loss_out, void* stream) {
   const char* who = "mi_shard_owner_bwd_dense";
   MI_REQUIRE(tab && sorted_rows && perm && n_total && X && dp && dm && dv && scratch && loss_out, "%s: null pointer",
              who);
-  MI_REQUIRE(n_slots >= 0 && n_slots < ((int64_t) 1 << 31) && rows >= 1 && n_dense >= 0 &&
+  MI_REQUIRE(n_slots >= 0 && n_slots < ((int64_t) 1 << 31) && n_ranks >= 1 && B >= 1 && n_dense >= 0 &&
                  n_dense + 2 <= FM_DENSE_THREADS && ld >= tab->dim + 2 + n_dense,
-             "%s: bad n_slots/rows/n_dense/ld", who);
+             "%s: bad n_slots/n_ranks/B/n_dense/ld", who);
   MI_REQUIRE(local_rows >= 1 && local_rows < (int64_t) 0x7FFFFFFFll, "%s: local_rows out of range", who);
+  const int64_t part = mi_shard_dense_part_floats(B, tab->dim, n_dense);
+  MI_REQUIRE((row_stride - B) * ld >= part, "%s: row_stride leaves no room for the combine launch's partials", who);
   mi_bwd_plan plan = {};
   plan.sorted_rows = sorted_rows;
   plan.perm = perm;
   plan.long_list = reinterpret_cast<int32_t*>(scratch);
-  scratch += n_slots + 2;
   plan.T = 1;  // entry p's sample is p itself: the sort's payload is the row of X
   plan.n_entries = n_slots;
   plan.n_bags = n_slots;
   plan.bag_len = 1;
   plan.total_rows = local_rows;
   plan.pool_mode = MI_POOL_SUM;
-  FmDenseRowsExtra extra;
-  FmDenseRowsArgs& a = extra.a;
+  FmDenseFinalExtra extra;
+  extra.blocks = 1;
+  FmDenseFinalArgs& a = extra.a;
   a.ct = 1;
   while (a.ct < n_dense + 2) a.ct <<= 1;
-  a.chunks = (int) dense_rows_chunks(rows);
-  extra.blocks = a.chunks;
-  a.X = X; a.ld = ld; a.rows = rows; a.dim = tab->dim; a.n_dense = n_dense;
-  a.part = scratch;
-  a.ticket = reinterpret_cast<int*>(scratch + (size_t) a.chunks * a.ct);
+  a.n_blocks = (int) (part / a.ct);
+  a.X = X; a.ld = ld; a.row_stride = row_stride; a.B = B; a.n_ranks = n_ranks; a.n_dense = n_dense;
   a.dp = dp; a.dm = dm; a.dv = dv; a.lr_t = dense_lr_t; a.lr_dev = dense_lr_dev;
   a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.loss_out = loss_out;
   return fm_bwd_apply_impl(who, &plan, tab, X + tab->dim, ld, X, ld, nullptr, opt, lr, lr_dev, beta1, beta2, eps,

@@ -489,41 +489,50 @@ def shard_route(toffs, ids, n_ranks, send, err=None):
 
 
 def shard_owner_fwd_sort(table, local_rows, toffs, rank, n_ranks, recv, B, partial, sorted_rows, perm, n_total,
-                         sched, lr, beta1, beta2, err=None):
+                         sched, lr, beta1, beta2, err=None, row_stride=None):
     """One launch: partial forward of every (source rank, sample) + sort of the received slots
-    (sorted_rows / perm [N*B*T] and n_total [1]; all None for the forward alone) + Adam schedule."""
+    (sorted_rows / perm [N*B*T] and n_total [1]; all None for the forward alone) + Adam schedule.
+    The payload of entry (s, b) is s*row_stride + b (row_stride defaults to B)."""
     T = toffs.numel() - 1
     if recv.numel() < n_ranks * shard_block_ints(B, T) or partial.numel() < n_ranks * B * (table.dim + 2):
         raise MiError("shard_owner_fwd_sort: buffer too small")
     if sorted_rows is not None and min(sorted_rows.numel(), perm.numel()) < n_ranks * B * T:
         raise MiError("shard_owner_fwd_sort: sort output too small")
     _lib.call('mi_shard_owner_fwd_sort', table.ref(), local_rows, _p(toffs), T, rank, n_ranks, _p(recv), B,
-              _p(partial), _p(sorted_rows), _p(perm), _p(n_total), _p(sched), lr, beta1, beta2, _p(err), _stream())
+              B if row_stride is None else row_stride, _p(partial), _p(sorted_rows), _p(perm), _p(n_total), _p(sched),
+              lr, beta1, beta2, _p(err), _stream())
 
 
-def fm_combine(partials, n_ranks, B, dim, dense, wd, bias, labels, gscale, X, logit=None):
+def shard_dense_part_floats(B, dim, n_dense):
+    """Floats the combine launch leaves behind the B sample rows (one dense-side partial per workgroup)."""
+    return int(_lib.load().mi_shard_dense_part_floats(B, dim, n_dense))
+
+
+def fm_combine(partials, n_ranks, B, dim, dense, wd, bias, labels, gscale, X, logit=None, part_out=None):
     n_dense = dense.shape[1] if dense is not None else 0
     if X.shape[0] < B or partials.numel() < n_ranks * B * (dim + 2):
         raise MiError("fm_combine: buffer too small")
+    if part_out is not None and part_out.numel() < shard_dense_part_floats(B, dim, n_dense):
+        raise MiError("fm_combine: part_out too small")
     _lib.call('mi_fm_combine', _p(partials), n_ranks, B, dim, _p(dense), n_dense, _p(wd), _p(bias), _p(labels),
-              gscale, _p(logit), _p(X), X.shape[1], _stream())
+              gscale, _p(logit), _p(X), X.shape[1], _p(part_out), _stream())
 
 
-def shard_bwd_scratch_floats(rows, n_dense, n_slots):
-    return int(_lib.load().mi_shard_bwd_scratch_floats(rows, n_dense, n_slots))
+def shard_bwd_scratch_floats(n_slots):
+    return int(_lib.load().mi_shard_bwd_scratch_floats(n_slots))
 
 
-def shard_owner_bwd_dense(table, local_rows, sorted_rows, perm, n_total, n_slots, X_all, opt, lr, beta1, beta2, eps, n_dense,
-                          dp, dm, dv, dense_lr_t, scratch, loss_out, lr_dev=None, dense_lr_dev=None):
+def shard_owner_bwd_dense(table, local_rows, sorted_rows, perm, n_total, n_slots, X_all, n_ranks, B, row_stride, opt,
+                          lr, beta1, beta2, eps, n_dense, dp, dm, dv, dense_lr_t, scratch, loss_out, lr_dev=None,
+                          dense_lr_dev=None):
     """One launch: sparse backward + fused optimizer over the owner's sorted entries, and the dense
-    side (Adam on dp, mean loss) over all rows of X_all."""
-    rows = X_all.shape[0]
-    if min(sorted_rows.numel(), perm.numel()) < n_slots or scratch.numel() < shard_bwd_scratch_floats(rows, n_dense, n_slots):
+    side (sum of all ranks' combine partials, Adam on dp, mean loss)."""
+    if min(sorted_rows.numel(), perm.numel()) < n_slots or scratch.numel() < shard_bwd_scratch_floats(n_slots) \
+            or X_all.shape[0] < n_ranks * row_stride:
         raise MiError("shard_owner_bwd_dense: buffer too small")
     _lib.call('mi_shard_owner_bwd_dense', table.ref(), local_rows, _p(sorted_rows), _p(perm), _p(n_total), n_slots,
-              _p(X_all),
-              X_all.shape[1], rows, opt, lr, _p(lr_dev), beta1, beta2, eps, n_dense, _p(dp), _p(dm), _p(dv),
-              dense_lr_t, _p(dense_lr_dev), _p(scratch), _p(loss_out), _stream())
+              _p(X_all), X_all.shape[1], n_ranks, B, row_stride, opt, lr, _p(lr_dev), beta1, beta2, eps, n_dense,
+              _p(dp), _p(dm), _p(dv), dense_lr_t, _p(dense_lr_dev), _p(scratch), _p(loss_out), _stream())
 
 
 def fm_dense_step_rows(X, dim, n_dense, dp, dm, dv, lr_t, beta1, beta2, eps, loss_out, lr_dev=None):

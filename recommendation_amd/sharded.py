@@ -21,11 +21,12 @@ fixed size, and FOUR launches; nothing on the host ever waits for the device:
   B. all-to-all  [N][B][D+2] fp32     owner -> requester: per SAMPLE sum v, sum |v|^2, sum w1
                                       (not per (sample, field))
   launch 3  combine: sum the owners' partials in rank order, logit, loss, dL/dlogit -> X rows
-  C. all-gather  [B][D+2+nd] fp32     every sample's S, dL/dlogit, loss row and dense features
-  launch 4  owner: sparse backward + fused optimizer | dense side over all N*B rows
+  C. all-gather  [B+e][D+2+nd] fp32   every sample's S, dL/dlogit, loss row and dense features, and
+                                      behind them the rank's dense-side partial sums
+  launch 4  owner: sparse backward + fused optimizer | dense side: all ranks' partials added
 
-After C every owner has what its sparse backward needs and every replica computes the dense-side
-gradients of all N*B samples itself, in the same order, so there is no all-reduce.  The sparse
+After C every owner has what its sparse backward needs and every replica adds the same dense-side
+partials in the same order, so there is no all-reduce and the replicas stay bit-identical.  The sparse
 backward and the fused optimizer run entirely on the owner: no gradient row crosses the fabric.
 Local compute goes through a small backend object so that the exchange logic can be exercised
 with gloo on CPU (tests plug in a numpy stand-in); the product backend is ``HipBackend`` and there
@@ -67,24 +68,30 @@ class HipBackend(object):
     def zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
-    def bwd_scratch(self, rows, n_slots):
-        return self.zeros((ops.shard_bwd_scratch_floats(rows, self.n_dense, n_slots),), torch.float32)
+    def bwd_scratch(self, n_slots):
+        return self.zeros((ops.shard_bwd_scratch_floats(n_slots),), torch.float32)
+
+    def extra_rows(self, B, ld):
+        """Rows behind the B sample rows of X that carry the combine launch's dense-side partials."""
+        return -(-ops.shard_dense_part_floats(B, self.dim, self.n_dense) // ld)
 
     # step pieces: one launch each ---------------------------------------------------------------
     def route(self, ids, send):
         ops.shard_route(self.toffs, ids, self.world, send, self.err)
 
-    def owner_forward(self, recv, B, partial, sorted_rows, perm, n_total, sched, lr, beta1, beta2):
+    def owner_forward(self, recv, B, row_stride, partial, sorted_rows, perm, n_total, sched, lr, beta1, beta2):
         ops.shard_owner_fwd_sort(self.table, max(self.local_rows, 1), self.toffs, self.rank, self.world, recv, B,
-                                 partial, sorted_rows, perm, n_total, sched, lr, beta1, beta2, self.err)
+                                 partial, sorted_rows, perm, n_total, sched, lr, beta1, beta2, self.err,
+                                 row_stride=row_stride)
 
     def combine(self, partials, B, dense, wd, bias, labels, gscale, X):
-        ops.fm_combine(partials, self.world, B, self.dim, dense, wd, bias, labels, gscale, X)
+        ops.fm_combine(partials, self.world, B, self.dim, dense, wd, bias, labels, gscale, X, part_out=X[B:])
 
-    def update(self, sorted_rows, perm, n_total, X_all, dp, dm, dv, lr, beta1, beta2, eps, sched, scratch, loss):
+    def update(self, sorted_rows, perm, n_total, X_all, B, row_stride, dp, dm, dv, lr, beta1, beta2, eps, sched,
+               scratch, loss):
         adam = self.opt == 'adam_tf'
         ops.shard_owner_bwd_dense(self.table, max(self.local_rows, 1), sorted_rows, perm, n_total,
-                                  sorted_rows.numel(), X_all,
+                                  sorted_rows.numel(), X_all, self.world, B, row_stride,
                                   _OPT[self.opt], lr, beta1, beta2, eps, self.n_dense, dp, dm, dv, 0.0, scratch, loss,
                                   lr_dev=sched if adam else None, dense_lr_dev=sched)
 
@@ -174,8 +181,10 @@ class ShardedFactorizationMachine(object):
         self.sorted_rows, self.perm = be.zeros((N * B * T,), i32), be.zeros((N * B * T,), i32)
         self.n_total = be.zeros((1,), i32)
         self.partial, self.partials_in = be.zeros((N, B, D + 2), f32), be.zeros((N, B, D + 2), f32)
-        self.X, self.X_all = be.zeros((B, self.ld), f32), be.zeros((N * B, self.ld), f32)
-        self.scratch = be.bwd_scratch(N * B, N * B * T)
+        # per rank: B sample rows, then the rows that carry its dense-side partials
+        self.rs = B + be.extra_rows(B, self.ld)
+        self.X, self.X_all = be.zeros((self.rs, self.ld), f32), be.zeros((N * self.rs, self.ld), f32)
+        self.scratch = be.bwd_scratch(N * B * T)
         self.loss = be.zeros((1,), f32)
         self._B = B
 
@@ -189,12 +198,13 @@ class ShardedFactorizationMachine(object):
     def phase_owner_forward(self):
         """self.recv -> self.partial [N][B][D+2] (exchange B: all-to-all into self.partials_in), and
         the sorted entries the backward will take."""
-        self.be.owner_forward(self.recv, self._B, self.partial, self.sorted_rows, self.perm, self.n_total, self.sched,
-                              self.lr, self.beta1, self.beta2)
+        self.be.owner_forward(self.recv, self._B, self.rs, self.partial, self.sorted_rows, self.perm, self.n_total,
+                              self.sched, self.lr, self.beta1, self.beta2)
         return self.partial
 
     def phase_combine(self, dense, labels):
-        """self.partials_in -> self.X [B][ld] (exchange C: all-gather into self.X_all)."""
+        """self.partials_in -> self.X [rs][ld]: B sample rows + dense-side partials (exchange C:
+        all-gather into self.X_all)."""
         B = self._B
         self.be.combine(self.partials_in, B, dense if self.n_dense else None, self.wd if self.n_dense else None,
                         self.bias, labels, 1.0 / (B * self.world), self.X)
@@ -202,8 +212,8 @@ class ShardedFactorizationMachine(object):
 
     def phase_update(self):
         """Sparse backward + optimizer on the owner, dense step on every replica."""
-        self.be.update(self.sorted_rows, self.perm, self.n_total, self.X_all, self.dp, self.dm, self.dv, self.lr,
-                       self.beta1, self.beta2, self.eps, self.sched, self.scratch, self.loss)
+        self.be.update(self.sorted_rows, self.perm, self.n_total, self.X_all, self._B, self.rs, self.dp, self.dm,
+                       self.dv, self.lr, self.beta1, self.beta2, self.eps, self.sched, self.scratch, self.loss)
 
     # -- one step over torch.distributed --------------------------------------------------------
     def _route_and_send(self, ids):
@@ -264,7 +274,7 @@ def lockstep_train_step(models, batches):
         m.phase_combine(dense, labels)
     for m in models:                                     # exchange C
         for s, ms in enumerate(models):
-            m.X_all[s * B:(s + 1) * B].copy_(ms.X)
+            m.X_all[s * m.rs:(s + 1) * m.rs].copy_(ms.X)
     for m in models:
         m.phase_update()
     return models[0].loss

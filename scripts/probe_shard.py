@@ -40,12 +40,12 @@ def timed(name, fn, reps=30):
 
 timed("route", lambda: m.phase_route(ids))
 be = m.be
-timed("owner forward alone", lambda: be.owner_forward(m.recv, B, m.partial, None, None, None, None, m.lr, m.beta1, m.beta2))
+timed("owner forward alone", lambda: be.owner_forward(m.recv, B, m.rs, m.partial, None, None, None, None, m.lr, m.beta1, m.beta2))
 timed("owner forward + sort", lambda: m.phase_owner_forward())
 m.partials_in.copy_(m.partial)
 timed("combine", lambda: m.phase_combine(dense, labels))
 for s in range(N):
-    m.X_all[s * B:(s + 1) * B].copy_(m.X)
+    m.X_all[s * m.rs:(s + 1) * m.rs].copy_(m.X)
 timed("owner backward + dense side", lambda: m.phase_update())
 valid = int(m.n_total.item())
 keep = m.n_total.clone()

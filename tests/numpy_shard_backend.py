@@ -35,8 +35,11 @@ class NumpyBackend(object):
     def zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype)
 
-    def bwd_scratch(self, rows, n_slots):
+    def bwd_scratch(self, n_slots):
         return torch.zeros((1,), dtype=torch.float32)
+
+    def extra_rows(self, B, ld):
+        return 0
 
     def first_local(self, t):
         return (int(self.toffs[t]) - self.rank + self.world - 1) // self.world
@@ -58,7 +61,8 @@ class NumpyBackend(object):
             for c in range(cnt.shape[0]):
                 cnt[c] = mine[64 * c:64 * c + 64].sum(0)
 
-    def owner_forward(self, recv, B, partial, sorted_rows, perm, n_total, sched, lr, beta1, beta2):
+    def owner_forward(self, recv, B, row_stride, partial, sorted_rows, perm, n_total, sched, lr, beta1, beta2):
+        assert row_stride == B
         R, P = _np(recv), _np(partial)
         slots_all = np.stack([self._split(R[s], B)[1] for s in range(self.world)])   # [N][T][B]
         D = self.dim
@@ -106,7 +110,8 @@ class NumpyBackend(object):
         if dense is not None:
             x[:, D + 2:D + 2 + self.n_dense] = _np(dense)
 
-    def update(self, sorted_rows, perm, n_total, X_all, dp, dm, dv, lr, beta1, beta2, eps, sched, scratch, loss):
+    def update(self, sorted_rows, perm, n_total, X_all, B, row_stride, dp, dm, dv, lr, beta1, beta2, eps, sched,
+               scratch, loss):
         x = _np(X_all)
         D, nd = self.dim, self.n_dense
         g = x[:, D]
