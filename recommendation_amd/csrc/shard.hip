@@ -46,8 +46,14 @@ __global__ __launch_bounds__(ROUTE_THREADS) void route_kernel(const int64_t* __r
     int o = -1, l = -1;
     if (id >= 0 && id < rows) {
       const int64_t g = base + id;
-      o = (int) (g % N);
-      l = (int) (g / N);
+      if (g < ((int64_t) 1 << 32)) {  // the usual case: a 32-bit division is a fraction of a 64-bit one
+        const uint32_t g32 = (uint32_t) g;
+        l = (int) (g32 / (uint32_t) N);
+        o = (int) (g32 - (uint32_t) l * (uint32_t) N);
+      } else {
+        o = (int) (g % N);
+        l = (int) (g / N);
+      }
     } else {
       bad = true;
     }
@@ -56,16 +62,18 @@ __global__ __launch_bounds__(ROUTE_THREADS) void route_kernel(const int64_t* __r
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  // a wave per (owner, table) row of 64 slots
-  for (int ot = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); ot < N * T; ot += ROUTE_THREADS / 64) {
-    const int o = ot / T, t = ot - o * T;
+  // a wave per (owner, table) row of 64 slots; the owners are dealt over the gridDim.y workgroups of a chunk
+  const int n_mine = (N - (int) blockIdx.y + (int) gridDim.y - 1) / (int) gridDim.y;
+  for (int ot = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); ot < n_mine * T; ot += ROUTE_THREADS / 64) {
+    const int oi = ot / T, t = ot - oi * T;
+    const int o = (int) blockIdx.y + oi * (int) gridDim.y;
     const bool mine = lane < nb && own[t * ROUTE_SAMPLES + lane] == o;
     int32_t* blk = send + (size_t) o * stride;
     if (lane < nb) blk[(size_t) n_chunks * T + (size_t) t * B + b0 + lane] = mine ? loc[t * ROUTE_SAMPLES + lane] : -1;
     const int cnt = __popcll(__ballot(mine));
     if (lane == 0) blk[chunk * T + t] = cnt;
   }
-  if (bad && err) atomicOr(err, MI_IDERR_RANGE);
+  if (bad && err && blockIdx.y == 0) atomicOr(err, MI_IDERR_RANGE);
 }
 
 // ---- owner side ------------------------------------------------------------------------------
@@ -827,11 +835,14 @@ extern "C" int mi_shard_route(const int64_t* table_offsets, int T, const void* i
   hipStream_t s = (hipStream_t) stream;
   const unsigned grid = (unsigned) mi_cdiv(B, ROUTE_SAMPLES);
   const size_t lds = (size_t) 2 * T * ROUTE_SAMPLES * sizeof(int32_t);
+  // enough workgroups for the chip: the owners of a chunk are shared by up to four of them
+  unsigned osplit = 1;
+  while (osplit < 4 && osplit * 2 <= (unsigned) n_ranks && grid * osplit < 256) osplit *= 2;
   if (idx_bits == 32)
-    hipLaunchKernelGGL(route_kernel<int32_t>, dim3(grid), dim3(ROUTE_THREADS), lds, s, table_offsets, T, ids, (int) B, n_ranks,
+    hipLaunchKernelGGL(route_kernel<int32_t>, dim3(grid, osplit), dim3(ROUTE_THREADS), lds, s, table_offsets, T, ids, (int) B, n_ranks,
                        mi_shard_block_ints(B, T), send, err);
   else
-    hipLaunchKernelGGL(route_kernel<int64_t>, dim3(grid), dim3(ROUTE_THREADS), lds, s, table_offsets, T, ids, (int) B, n_ranks,
+    hipLaunchKernelGGL(route_kernel<int64_t>, dim3(grid, osplit), dim3(ROUTE_THREADS), lds, s, table_offsets, T, ids, (int) B, n_ranks,
                        mi_shard_block_ints(B, T), send, err);
   MI_LAUNCH_CHECK();
   return MI_OK;
