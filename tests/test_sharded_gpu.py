@@ -51,6 +51,39 @@ def test_sharded_equals_single_gpu(dev, N, opt):
     assert rel_err(shards[0].dp.cpu().numpy(), single.dp.cpu().numpy()) <= tol
 
 
+def test_sharded_equals_single_gpu_ragged_batch(dev):
+    """A batch that fills neither the last 64-sample chunk nor a 256-slot unit, three ranks, SGD:
+    the scalar slot pass and the chunk tails."""
+    from recommendation_amd.fm import FactorizationMachine
+    from recommendation_amd.sharded import ShardedFactorizationMachine, lockstep_train_step
+    rows, N, B, opt = [1460, 5, 30001, 24, 3], 3, 300, "sgd"
+    ref = ofm.State(rows, 16, 13, seed=2, opt=opt)
+    single = FactorizationMachine(rows, 16, 13, device=dev, opt=opt, lr=1e-2)
+    single.load_state(ref)
+    shards = [ShardedFactorizationMachine(rows, 16, 13, device=dev, opt=opt, lr=1e-2, rank=r, world=N)
+              for r in range(N)]
+    for m in shards:
+        m.load_state(ref)
+    for step in range(3):
+        parts = [ofm.synthetic_batch(B, rows, 13, seed=50 * step + r, dist='zipf') for r in range(N)]
+        batches = [tuple(torch.from_numpy(a).to(dev) for a in p) for p in parts]
+        whole = tuple(torch.from_numpy(np.concatenate([p[k] for p in parts])).to(dev) for k in range(3))
+        l1 = float(single.train_step(*whole).item())
+        lN = float(lockstep_train_step(shards, batches).item())
+        assert abs(l1 - lN) <= 1e-5 * abs(l1)
+        for m in shards:
+            m.be.check()
+    V, w1 = np.zeros_like(ref.V), np.zeros_like(ref.w1)
+    for r, m in enumerate(shards):
+        v, w = m.be.rows()
+        V[r::N], w1[r::N] = v.cpu().numpy(), w.cpu().numpy()
+    assert rel_err(V, single.V.cpu().numpy()) <= 1e-5
+    assert rel_err(w1, single.w1.cpu().numpy()) <= 1e-5
+    for m in shards:
+        assert torch.equal(m.dp, shards[0].dp)
+    assert rel_err(shards[0].dp.cpu().numpy(), single.dp.cpu().numpy()) <= 1e-4
+
+
 def test_sharded_equals_single_gpu_full_batch_hot_rows(dev):
     """Batch 8192 per rank with one-row and three-row tables: an owner receives far more entries of
     one table than one LDS sort holds, and single keys with more than 8192 entries."""
