@@ -455,6 +455,12 @@ int mi_head_bwd(const float* g, const float* w, const void* h, int64_t ld_h, int
 /* out (bf16) = in (fp32). */
 int mi_cast_bf16(const float* in, int64_t n, void* out, void* stream);
 
+/* dst[c][r] = src[r][c], bf16, R x C.  A weight kept in both orientations lets the data-gradient
+ * contraction dX = dY*W read W row-stored like the forward does (the reduction-major operand path
+ * of mi_gemm_bf16 is the slower one); 2 MB per 1024 x 1024 layer and step. */
+int mi_transpose_bf16(const void* src, int64_t ld_src, int R, int C, void* dst, int64_t ld_dst,
+                      void* stream);
+
 /* Gradient of the cross network's input x0 (x_{l+1} = x0*u_l + x_l, L layers, L <= 8):
  *   out[m][n] (fp32) = dx[0][m][n] + sum_{l < L} dx[l+1][m][n] * u[l][m][n]
  * dx[0..L] and u[0..L-1] are host arrays of device pointers to bf16 [M][ld] tensors (what the

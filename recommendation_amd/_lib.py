@@ -87,6 +87,7 @@ _SIGNATURES = {
     'mi_head_fwd': (c_int, [P, c_int64, c_int, P, P, P, c_float, c_int64, P, P, P, P]),
     'mi_head_bwd': (c_int, [P, P, P, c_int64, c_int, c_int64, P, c_int64, c_int, P, c_int64, P]),
     'mi_cast_bf16': (c_int, [P, c_int64, P, P]),
+    'mi_transpose_bf16': (c_int, [P, c_int64, c_int, c_int, P, c_int64, P]),
     'mi_cross_input_grad': (c_int, [P, P, c_int, c_int64, c_int, c_int64, P, c_int64, P]),
     'mi_din_lau_build': (c_int, [P, c_int64, c_int, P, P, c_int, P, c_int64, c_int, P, P, P, c_int64, P, P]),
     'mi_din_lau_pool': (c_int, [P, P, P, c_int64, c_int, c_int, P, c_int64, P]),

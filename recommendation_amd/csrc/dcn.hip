@@ -241,6 +241,41 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   *reinterpret_cast<ushort4*>(out + i) = u;
 }
 
+// dst[c][r] = src[r][c] (bf16), 64 x 64 tiles through LDS so that both sides move whole rows
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned short* __restrict__ src, int64_t ld_src,
+                                                            int R, int C, unsigned short* __restrict__ dst,
+                                                            int64_t ld_dst) {
+  __shared__ unsigned short tile[64][66];  // 66: the column reads below fall on different banks
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int q = (threadIdx.x & 15) * 4, rr = threadIdx.x >> 4;  // four elements per thread and pass, 16 rows per pass
+  const bool vec = ((ld_src | ld_dst) & 3) == 0 && (((uintptr_t) src | (uintptr_t) dst) & 7) == 0 && r0 + 64 <= R && c0 + 64 <= C;
+  if (vec) {
+    ushort4 v[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) v[p] = *reinterpret_cast<const ushort4*>(src + (int64_t) (r0 + rr + 16 * p) * ld_src + c0 + q);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      unsigned short* t = &tile[rr + 16 * p][q];
+      t[0] = v[p].x; t[1] = v[p].y; t[2] = v[p].z; t[3] = v[p].w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int cr = rr + 16 * p;  // row of dst = column of src
+      ushort4 o;
+      o.x = tile[q][cr]; o.y = tile[q + 1][cr]; o.z = tile[q + 2][cr]; o.w = tile[q + 3][cr];
+      *reinterpret_cast<ushort4*>(dst + (int64_t) (c0 + cr) * ld_dst + r0 + q) = o;
+    }
+    return;
+  }
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4)
+    if (r0 + i < R && c0 + tx < C) tile[i][tx] = src[(int64_t) (r0 + i) * ld_src + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4)
+    if (c0 + i < C && r0 + tx < R) dst[(int64_t) (c0 + i) * ld_dst + r0 + tx] = tile[tx][i];
+}
+
 struct CrossPtrs {
   const unsigned short* dx[9];
   const unsigned short* u[8];
@@ -346,6 +381,15 @@ extern "C" int mi_cast_bf16(const float* in, int64_t n, void* out, void* stream)
   MI_REQUIRE(in && out && n >= 4 && n % 4 == 0 && a16(in) && a8(out), "mi_cast_bf16: bad arguments");
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned) mi_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t) stream, in, n,
                      (unsigned short*) out);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_transpose_bf16(const void* src, int64_t ld_src, int R, int C, void* dst, int64_t ld_dst,
+                                 void* stream) {
+  MI_REQUIRE(src && dst && R >= 1 && C >= 1 && ld_src >= C && ld_dst >= R, "mi_transpose_bf16: bad arguments");
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned) mi_cdiv(C, 64), (unsigned) mi_cdiv(R, 64)), dim3(256), 0,
+                     (hipStream_t) stream, (const unsigned short*) src, ld_src, R, C, (unsigned short*) dst, ld_dst);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

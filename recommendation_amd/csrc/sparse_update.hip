@@ -677,17 +677,24 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
       const int piece_hi = end < lo + LONG_CHUNK ? end : lo + LONG_CHUNK;
       block_sum<VEC>(pl, src, lanes, groups, piece_lo, piece_hi, red, reds);
       float* mine = parts + ((size_t) bid * 2 + (h < 0 ? 0 : 1)) * dimv;
+      // The partial goes out with device-scope stores (written through to where every XCD sees
+      // it) and is acknowledged before the ticket is taken.  A device-wide fence would do the same
+      // but also writes back this XCD's whole L2, which the row updates around keep full of dirty
+      // lines: that cost more than the piecewise sum saved.
       if (sub == 0) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) mine[c * VEC + k] = red[c * VEC + k];
-        if (c == 0) mine[dimv - 1] = reds[0];
+        for (int k = 0; k < VEC; ++k)
+          __hip_atomic_store(mine + c * VEC + k, red[c * VEC + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c == 0) __hip_atomic_store(mine + dimv - 1, reds[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      __threadfence();  // the partial is visible device-wide before the ticket is taken
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (threadIdx.x == 0) sh_last = atomicAdd(&ticket[first_chunk], 1) == last_chunk - first_chunk ? 1 : 0;
+      if (threadIdx.x == 0)
+        sh_last = __hip_atomic_fetch_add(&ticket[first_chunk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                          last_chunk - first_chunk
+                      ? 1 : 0;
       __syncthreads();
       if (!sh_last) continue;
-      __threadfence();
       // the last piece to arrive adds the partials in position order and applies the update
       if (sub == 0) {
         typename Upd::template Regs<VEC> regs;
@@ -699,12 +706,12 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
         for (int ch = first_chunk; ch <= last_chunk; ++ch) {
           const float* p = parts + ((size_t) ch * 2 + (ch == first_chunk ? 1 : 0)) * dimv;
 #pragma unroll
-          for (int k = 0; k < VEC; ++k) g[k] += __builtin_nontemporal_load(p + c * VEC + k);
-          gs += __builtin_nontemporal_load(p + dimv - 1);
+          for (int k = 0; k < VEC; ++k) g[k] += __hip_atomic_load(p + c * VEC + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gs += __hip_atomic_load(p + dimv - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         upd.template finish<VEC>((int64_t) row, c, lanes, regs, g, gs);
       }
-      if (threadIdx.x == 0) atomicExch(&ticket[first_chunk], 0);
+      if (threadIdx.x == 0) __hip_atomic_store(&ticket[first_chunk], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
     }
     return;

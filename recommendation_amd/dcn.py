@@ -36,6 +36,8 @@ class _Dense(object):
         self.m, self.v = torch.zeros_like(self.w), torch.zeros_like(self.w)
         self.grad = torch.zeros_like(self.w)
         self.h = self.w.to(torch.bfloat16) if bf16_copy else None
+        # the same matrix the other way round, [in][out]: what the data-gradient contraction reads
+        self.hT = self.h.t().contiguous() if bf16_copy else None
 
 
 class DCNv2(object):
@@ -117,6 +119,7 @@ class DCNv2(object):
         self.out.w[K] = float(st.b_out[0])
         for p in self.Wc + self.Wm:
             ops.cast_bf16(p.w, p.h)
+            ops.transpose_bf16(p.h, p.hT)
 
     # -- buffers ------------------------------------------------------------------------------
     def _splits(self, n_out, k_in, B):
@@ -188,6 +191,7 @@ class DCNv2(object):
         ops.gemm_bf16(dY, X, ops.MI_EPI_SLAB, a_rm=True, b_rm=True, M=n_out, N=k_in, K=dY.shape[0], k_splits=s,
                       out=self.slab[:s * n_out * k_in].view(s, n_out, k_in))
         self._apply(p, s, n_out * k_in, n_out * k_in)
+        ops.transpose_bf16(p.h, p.hT)
 
     def _bias_step(self, p, dY):
         n = p.w.numel()
@@ -214,25 +218,25 @@ class DCNv2(object):
             dz = self.dz[i]
             inp = self.h[i - 1] if i > 0 else self.x[-1]
             if i > 0:
-                ops.gemm_bf16(dz, self.Wm[i].h, ops.MI_EPI_MASK, b_rm=True, out=self.dz[i - 1], in0=self.h[i - 1])
+                ops.gemm_bf16(dz, self.Wm[i].hT, ops.MI_EPI_MASK, out=self.dz[i - 1], in0=self.h[i - 1])
             else:
                 # into the cross network: dx_L and du_{L-1} = dx_L * x0
                 L = self.n_cross
                 if L:
-                    ops.gemm_bf16(dz, self.Wm[0].h, ops.MI_EPI_CROSS_BWD, b_rm=True, out=self.dx[L], out1=self.du[L & 1],
+                    ops.gemm_bf16(dz, self.Wm[0].hT, ops.MI_EPI_CROSS_BWD, out=self.dx[L], out1=self.du[L & 1],
                                   in0=x0)
                 else:
-                    ops.gemm_bf16(dz, self.Wm[0].h, ops.MI_EPI_CROSS_BWD, b_rm=True, out=self.dx[0])
+                    ops.gemm_bf16(dz, self.Wm[0].hT, ops.MI_EPI_CROSS_BWD, out=self.dx[0])
             self._weight_step(self.Wm[i], dz, inp)
             self._bias_step(self.bm[i], dz)
         # cross layers, last first: dx_l = du_l W_l + dx_{l+1}, du_{l-1} = dx_l * x0
         for l in reversed(range(self.n_cross)):
             du = self.du[(l + 1) & 1]
             if l > 0:
-                ops.gemm_bf16(du, self.Wc[l].h, ops.MI_EPI_CROSS_BWD, b_rm=True, out=self.dx[l], in1=self.dx[l + 1],
+                ops.gemm_bf16(du, self.Wc[l].hT, ops.MI_EPI_CROSS_BWD, out=self.dx[l], in1=self.dx[l + 1],
                               out1=self.du[l & 1], in0=x0)
             else:
-                ops.gemm_bf16(du, self.Wc[0].h, ops.MI_EPI_CROSS_BWD, b_rm=True, out=self.dx[0], in1=self.dx[1])
+                ops.gemm_bf16(du, self.Wc[0].hT, ops.MI_EPI_CROSS_BWD, out=self.dx[0], in1=self.dx[1])
             self._weight_step(self.Wc[l], du, self.x[l])
             self._bias_step(self.bc[l], du)
         # d x0 = dx_0 + sum_l dx_{l+1} * u_l, one pass over the stored tensors

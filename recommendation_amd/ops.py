@@ -616,6 +616,14 @@ def cast_bf16(src, dst):
     _lib.call('mi_cast_bf16', _p(src), src.numel(), _p(dst), _stream())
 
 
+def transpose_bf16(src, dst):
+    """dst[c][r] = src[r][c] for 2-D bf16 tensors with contiguous rows."""
+    R, C = src.shape
+    if dst.shape[0] < C or dst.shape[1] < R or src.stride(1) != 1 or dst.stride(1) != 1:
+        raise MiError("transpose_bf16: dst must be [C][R] with contiguous rows")
+    _lib.call('mi_transpose_bf16', _p(src), src.stride(0), R, C, _p(dst), dst.stride(0), _stream())
+
+
 # ----------------------------------------------------------------------------- DIN local activation unit
 def din_lau_build(E, hist, qid, lengths, A, ids_all, q_out=None, err=None):
     B, L = hist.shape

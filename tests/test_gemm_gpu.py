@@ -134,3 +134,13 @@ def test_rejects_bad_shapes(dev):
     out = torch.zeros((1, 64, 64), dtype=torch.float32, device=dev)
     with pytest.raises(MiError):
         ops.gemm_bf16(A, A, ops.MI_EPI_SLAB, out=out)          # K = 100 is not a multiple of 64
+
+
+@pytest.mark.parametrize("shape", [(1024, 448), (448, 448), (130, 70), (64, 64), (1, 5)])
+def test_transpose_bf16_bit_exact(dev, shape):
+    from recommendation_amd import ops
+    R, C = shape
+    src = torch.randn((R, C), device=dev).to(torch.bfloat16)
+    dst = torch.zeros((C, R), dtype=torch.bfloat16, device=dev)
+    ops.transpose_bf16(src, dst)
+    assert torch.equal(dst, src.t().contiguous())
