@@ -126,6 +126,59 @@ __global__ __launch_bounds__(256) void slab_adam_kernel(const float* __restrict_
   }
 }
 
+// The same for a short vector under many slabs (a bias under 256 row slices): one thread per four
+// elements would walk all the slabs alone, so 16 lanes share them - lane l adds slabs l, l+16, ...
+// in order, then the 16 partial sums are added in lane order.  A fixed order for a given S.
+__global__ __launch_bounds__(256) void slab_adam_small_kernel(const float* __restrict__ slab, int S, int64_t n,
+                                                             int64_t slab_stride, float* __restrict__ w,
+                                                             float* __restrict__ m, float* __restrict__ v, float lr_t,
+                                                             const float* __restrict__ lr_dev, float b1, float b2,
+                                                             float eps, unsigned short* __restrict__ w_bf16,
+                                                             float* __restrict__ grad_out) {
+  __shared__ float4 sh[16][16];
+  const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int64_t i = ((int64_t) blockIdx.x * 16 + col) * 4;
+  const bool live = i < n;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    for (int s0 = lane; s0 < S; s0 += 16 * 8) {
+      float4 p[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int s = s0 + 16 * j;
+        p[j] = s < S ? *reinterpret_cast<const float4*>(slab + (int64_t) s * slab_stride + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { g.x += p[j].x; g.y += p[j].y; g.z += p[j].z; g.w += p[j].w; }
+    }
+  }
+  sh[lane][col] = g;
+  __syncthreads();
+  if (lane != 0 || !live) return;
+  for (int l = 1; l < 16; ++l) { const float4 p = sh[l][col]; g.x += p.x; g.y += p.y; g.z += p.z; g.w += p.w; }
+  if (grad_out) *reinterpret_cast<float4*>(grad_out + i) = g;
+  if (!w) return;
+  const float alpha = lr_dev ? lr_dev[0] : lr_t;
+  float4 wi = *reinterpret_cast<const float4*>(w + i);
+  float4 mi = *reinterpret_cast<const float4*>(m + i);
+  float4 vi = *reinterpret_cast<const float4*>(v + i);
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+#define ADAM1(c)                                   \
+  mi.c += (g.c - mi.c) * omb1;                     \
+  vi.c += (g.c * g.c - vi.c) * omb2;               \
+  wi.c -= (mi.c * alpha) / (sqrtf(vi.c) + eps);
+  ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+  *reinterpret_cast<float4*>(w + i) = wi;
+  *reinterpret_cast<float4*>(m + i) = mi;
+  *reinterpret_cast<float4*>(v + i) = vi;
+  if (w_bf16) {
+    ushort4 u;
+    u.x = mi_f2bf(wi.x); u.y = mi_f2bf(wi.y); u.z = mi_f2bf(wi.z); u.w = mi_f2bf(wi.w);
+    *reinterpret_cast<ushort4*>(w_bf16 + i) = u;
+  }
+}
+
 // Output layer: logit = h . w + bias; BCE-with-logits loss row; g = dL/dlogit.  A group of `lpr`
 // lanes (a power of two <= 64, 4 columns per lane and pass) per sample.
 __global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned short* __restrict__ h, int64_t ld, int K,
@@ -341,9 +394,14 @@ extern "C" int mi_slab_adam(const float* slab, int n_slabs, int64_t n, int64_t s
              "mi_slab_adam: slabs must be 16-byte aligned, n a multiple of 4");
   MI_REQUIRE((w && m && v && a16(w) && a16(m) && a16(v)) || (!w && grad_out), "mi_slab_adam: need w, m, v or grad_out");
   MI_REQUIRE((!w_bf16 || a8(w_bf16)) && (!grad_out || a16(grad_out)), "mi_slab_adam: misaligned output");
-  hipLaunchKernelGGL(slab_adam_kernel, dim3((unsigned) mi_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t) stream, slab,
-                     n_slabs, n, slab_stride, w, m, v, lr_t, lr_dev, beta1, beta2, eps, (unsigned short*) w_bf16,
-                     grad_out);
+  if (n <= 16384 && n_slabs >= 32)  // a few workgroups' worth of elements under many slabs
+    hipLaunchKernelGGL(slab_adam_small_kernel, dim3((unsigned) mi_cdiv(n / 4, 16)), dim3(256), 0, (hipStream_t) stream,
+                       slab, n_slabs, n, slab_stride, w, m, v, lr_t, lr_dev, beta1, beta2, eps,
+                       (unsigned short*) w_bf16, grad_out);
+  else
+    hipLaunchKernelGGL(slab_adam_kernel, dim3((unsigned) mi_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t) stream, slab,
+                       n_slabs, n, slab_stride, w, m, v, lr_t, lr_dev, beta1, beta2, eps, (unsigned short*) w_bf16,
+                       grad_out);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
