@@ -78,6 +78,7 @@ class DIN(object):
             p.w.zero_()
             p.w[:w.shape[0], :w.shape[1]] = torch.from_numpy(w).to(dev)
             ops.cast_bf16(p.w, p.h)
+            ops.transpose_bf16(p.h, p.hT)
         for p, b in ((self.b1, st.b1), (self.b2, st.b2)):
             p.w.zero_()
             p.w[:b.shape[0]] = torch.from_numpy(b).to(dev)
@@ -154,6 +155,7 @@ class DIN(object):
         ops.gemm_bf16(dY, X, ops.MI_EPI_SLAB, a_rm=True, b_rm=True, M=n_out, N=k_in, K=dY.shape[0], k_splits=s,
                       out=self.slab[:s * n_out * k_in].view(s, n_out, k_in))
         self._apply(p, s, n_out * k_in, n_out * k_in)
+        ops.transpose_bf16(p.h, p.hT)
 
     def _bias_step(self, p, dY):
         n = p.w.numel()
@@ -179,10 +181,10 @@ class DIN(object):
         part.zero_()
         ops.head_bwd(self.da, self.w3.w[:self.h2p], self.H2, self.dH2, self.vec_slices, part)
         self._apply(self.w3, self.vec_slices, self.h2p + 4, self.h2p + 4)
-        ops.gemm_bf16(self.dH2, self.W2.h, ops.MI_EPI_MASK, b_rm=True, out=self.dZ1, in0=self.H1)
+        ops.gemm_bf16(self.dH2, self.W2.hT, ops.MI_EPI_MASK, out=self.dZ1, in0=self.H1)
         self._weight_step(self.W2, self.dH2, self.H1)
         self._bias_step(self.b2, self.dH2)
-        ops.gemm_bf16(self.dZ1, self.W1.h, ops.MI_EPI_MASK, b_rm=True, out=self.dA)
+        ops.gemm_bf16(self.dZ1, self.W1.hT, ops.MI_EPI_MASK, out=self.dA)
         self._weight_step(self.W1, self.dZ1, self.A)
         self._bias_step(self.b1, self.dZ1)
         # embedding rows: per-position gradients, then sort by row + fixed-order sums + row-wise Adagrad
