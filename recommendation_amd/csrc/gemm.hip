@@ -208,13 +208,111 @@ __device__ __forceinline__ void epi_apply(const mi_gemm_epilogue& e, int64_t M, 
   }
 }
 
+// The same with the mode and its optional tensors known at compile time (F0, F1 per mode:
+// BIAS_ACT: F0 = ReLU; CROSS_FWD: F0 = out1 wanted; MASK: F0 = in0 given; CROSS_BWD: F0 = out1 (and
+// in0), F1 = in1 given).  The run-time switch above puts a branch around every element, and at
+// every join the compiler has to wait for ALL outstanding memory operations, the previous rows'
+// stores included: measured, an input tile cost 17 us per 256 x 256 tile that way.  Without
+// branches the waits are counted and loads run ahead of stores.
+template <int MODE, bool F0, bool F1>
+struct EpiInT {
+  ushort4 p0, p1;
+};
+template <int MODE, bool F0, bool F1>
+__device__ __forceinline__ void epi_load_t(const mi_gemm_epilogue& e, int64_t m, int64_t n, ushort4& p0, ushort4& p1) {
+  if constexpr (MODE == MI_EPI_CROSS_FWD) {
+    p0 = ld_u4(e.in0, e.ld_in0, m, n);
+    p1 = ld_u4(e.in1, e.ld_in1, m, n);
+  } else if constexpr (MODE == MI_EPI_MASK) {
+    if constexpr (F0) p0 = ld_u4(e.in0, e.ld_in0, m, n);
+  } else if constexpr (MODE == MI_EPI_CROSS_BWD) {
+    if constexpr (F0) p0 = ld_u4(e.in0, e.ld_in0, m, n);
+    if constexpr (F1) p1 = ld_u4(e.in1, e.ld_in1, m, n);
+  }
+}
+template <int MODE, bool F0, bool F1>
+__device__ __forceinline__ void epi_apply_t(const mi_gemm_epilogue& e, int64_t M, int z, int64_t m, int64_t n, float4 v,
+                                            ushort4 p0, ushort4 p1, float4 bias) {
+  if constexpr (MODE == MI_EPI_SLAB) {
+    float* o = reinterpret_cast<float*>(e.out) + ((int64_t) z * M + m) * e.ld_out + n;
+    *reinterpret_cast<float4*>(o) = v;
+  } else if constexpr (MODE == MI_EPI_BIAS_ACT) {
+    v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+    if constexpr (F0) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    st_bf4(e.out, e.ld_out, m, n, v);
+  } else if constexpr (MODE == MI_EPI_CROSS_FWD) {
+    v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+    if constexpr (F0) st_bf4(e.out1, e.ld_out1, m, n, v);
+    const float4 x0 = bf4(p0), xl = bf4(p1);
+    st_bf4(e.out, e.ld_out, m, n,
+           make_float4(fmaf(x0.x, v.x, xl.x), fmaf(x0.y, v.y, xl.y), fmaf(x0.z, v.z, xl.z), fmaf(x0.w, v.w, xl.w)));
+  } else if constexpr (MODE == MI_EPI_MASK) {
+    if constexpr (F0) {
+      const float4 h = bf4(p0);
+      v.x = h.x > 0.f ? v.x : 0.f; v.y = h.y > 0.f ? v.y : 0.f;
+      v.z = h.z > 0.f ? v.z : 0.f; v.w = h.w > 0.f ? v.w : 0.f;
+    }
+    st_bf4(e.out, e.ld_out, m, n, v);
+  } else {  // MI_EPI_CROSS_BWD
+    if constexpr (F1) {
+      const float4 r = bf4(p1);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    st_bf4(e.out, e.ld_out, m, n, v);
+    if constexpr (F0) {
+      const float4 x0 = bf4(p0);
+      st_bf4(e.out1, e.ld_out1, m, n, make_float4(v.x * x0.x, v.y * x0.y, v.z * x0.z, v.w * x0.w));
+    }
+  }
+}
+
+// Epilogue of a wave's FM x FN fragments for a tile that lies wholly inside the matrix (no bounds
+// checks), mode fixed at compile time.  Fragment rows go two at a time and the input loads of the
+// next pair are issued before the stores of this one.
+template <int MODE, bool F0, bool F1, int FM, int FN, class Acc>
+__device__ __forceinline__ void epilogue_interior(const GemmArgs& a, Acc& acc, char* scratch, int ep_row, int64_t m_base,
+                                                  int64_t n, int z, int lane, float4 bias) {
+  // two input tensors: one fragment row at a time, or the accumulators and two pairs' inputs do not fit the registers
+  constexpr bool TWO_IN = MODE == MI_EPI_CROSS_FWD || (MODE == MI_EPI_CROSS_BWD && F0 && F1);
+  constexpr int CH = TWO_IN ? 1 : 2, NCH = FM / CH;
+  ushort4 p0[NCH][CH][4], p1[NCH][CH][4];
+  auto load_chunk = [&](int c) {
+#pragma unroll
+    for (int ii = 0; ii < CH; ++ii)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        epi_load_t<MODE, F0, F1>(a.e, m_base + (c * CH + ii) * 16 + q * 4 + (lane >> 4), n, p0[c][ii][q], p1[c][ii][q]);
+  };
+  load_chunk(0);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) load_chunk(c + 1);
+#pragma unroll
+    for (int ii = 0; ii < CH; ++ii) {
+      const int i = c * CH + ii;
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        *reinterpret_cast<f4v*>(scratch + (lane & 15) * ep_row + (j * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = q * 4 + (lane >> 4);
+        const f4v v = *reinterpret_cast<const f4v*>(scratch + row * ep_row + (lane & 15) * 16);
+        epi_apply_t<MODE, F0, F1>(a.e, a.M, z, m_base + i * 16 + row, n, make_float4(v.x, v.y, v.z, v.w), p0[c][ii][q],
+                                  p1[c][ii][q], bias);
+      }
+    }
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <bool A_TR, bool B_TR, int WM, int WN, int FM, int FN, int STAGES>
-__global__ __launch_bounds__(WM* WN * 64, 1) void gemm_bf16_kernel(GemmArgs a) {
+__global__ __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) void gemm_bf16_kernel(GemmArgs a) {
   // a wave owns FM x FN fragments of 16x16; the workgroup is WM x WN waves
   constexpr int NWAVES = WM * WN, BM = 16 * FM * WM, BN = 16 * FN * WN;
   constexpr int A_SUB = BM / 128, B_SUB = BN / 128;
@@ -331,8 +429,30 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_bf16_kernel(GemmArgs a) {
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
   if (n_ok && a.e.bias && (a.e.mode == MI_EPI_BIAS_ACT || a.e.mode == MI_EPI_CROSS_FWD))
     bias = *reinterpret_cast<const float4*>(a.e.bias + n);
-  // four fragment rows at a time: all their input loads first (one memory latency for the lot,
-  // not one per row), then transpose + arithmetic + stores
+  if (m0 + BM <= a.M && n0 + BN <= a.N) {  // uniform over the workgroup
+    const int64_t mb = m0 + (int64_t) wr * FM * 16;
+    const mi_gemm_epilogue& e = a.e;
+#define EPI(MODE, F0, F1) epilogue_interior<MODE, F0, F1, FM, FN>(a, acc, scratch, EP_ROW, mb, n, z, lane, bias)
+    switch (e.mode) {
+      case MI_EPI_SLAB: EPI(MI_EPI_SLAB, false, false); break;
+      case MI_EPI_BIAS_ACT:
+        if (e.flags & MI_EPI_RELU) EPI(MI_EPI_BIAS_ACT, true, false); else EPI(MI_EPI_BIAS_ACT, false, false);
+        break;
+      case MI_EPI_CROSS_FWD:
+        if (e.out1) EPI(MI_EPI_CROSS_FWD, true, false); else EPI(MI_EPI_CROSS_FWD, false, false);
+        break;
+      case MI_EPI_MASK:
+        if (e.in0) EPI(MI_EPI_MASK, true, false); else EPI(MI_EPI_MASK, false, false);
+        break;
+      default:  // MI_EPI_CROSS_BWD
+        if (e.out1) { if (e.in1) EPI(MI_EPI_CROSS_BWD, true, true); else EPI(MI_EPI_CROSS_BWD, true, false); }
+        else { if (e.in1) EPI(MI_EPI_CROSS_BWD, false, true); else EPI(MI_EPI_CROSS_BWD, false, false); }
+        break;
+    }
+#undef EPI
+    return;
+  }
+  // a tile on the matrix's edge: every position checked, mode looked up per element
   constexpr int CH = 4;
   static_assert(FM % CH == 0, "wave tile");
 #pragma unroll
@@ -391,6 +511,8 @@ int dispatch_gemm(GemmArgs& g, int splits, hipStream_t s) {
   // transposing reads and 241 VGPRs lose, and narrow outputs do not fill its 256 columns.
   const int64_t big = mi_cdiv(g.M, 256) * mi_cdiv(g.N, 256) * splits;
   const bool fills = mi_cdiv(g.N, 256) * 256 * 100 <= g.N * 115;  // at most 15 % of the columns are padding
+  const char* force = getenv("MI_DBG_GEMM_TILE");  // TEMPORARY probe switch
+  if (force && force[0] == 's') return launch_gemm<A_TR, B_TR, 2, 2, 4, 4, 2>(g, splits, s);
   if (!A_TR && big >= 128 && fills && (!B_TR || g.N >= 512)) return launch_gemm<A_TR, B_TR, 2, 4, 8, 4, 2>(g, splits, s);
   return launch_gemm<A_TR, B_TR, 2, 2, 4, 4, 2>(g, splits, s);
 }
