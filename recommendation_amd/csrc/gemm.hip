@@ -271,9 +271,9 @@ __device__ __forceinline__ void epi_apply_t(const mi_gemm_epilogue& e, int64_t M
 // Epilogue of a wave's FM x FN fragments for a tile that lies wholly inside the matrix (no bounds
 // checks), mode fixed at compile time.  Fragment rows go two at a time and the input loads of the
 // next pair are issued before the stores of this one.
-template <int MODE, bool F0, bool F1, int FM, int FN, class Acc>
+template <int MODE, bool F0, bool F1, bool NGUARD, int FM, int FN, class Acc>
 __device__ __forceinline__ void epilogue_interior(const GemmArgs& a, Acc& acc, char* scratch, int ep_row, int64_t m_base,
-                                                  int64_t n, int z, int lane, float4 bias) {
+                                                  int64_t n, bool n_ok, int z, int lane, float4 bias) {
   // two input tensors: one fragment row at a time, or the accumulators and two pairs' inputs do not fit the registers
   constexpr bool TWO_IN = MODE == MI_EPI_CROSS_FWD || (MODE == MI_EPI_CROSS_BWD && F0 && F1);
   constexpr int CH = TWO_IN ? 1 : 2, NCH = FM / CH;
@@ -283,7 +283,8 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& a, Acc& acc, c
     for (int ii = 0; ii < CH; ++ii)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        epi_load_t<MODE, F0, F1>(a.e, m_base + (c * CH + ii) * 16 + q * 4 + (lane >> 4), n, p0[c][ii][q], p1[c][ii][q]);
+        if (!NGUARD || n_ok)  // NGUARD: the tile hangs over the last column; lanes beyond it only help with the transposes
+          epi_load_t<MODE, F0, F1>(a.e, m_base + (c * CH + ii) * 16 + q * 4 + (lane >> 4), n, p0[c][ii][q], p1[c][ii][q]);
   };
   load_chunk(0);
 #pragma unroll
@@ -295,13 +296,16 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& a, Acc& acc, c
 #pragma unroll
       for (int j = 0; j < FN; ++j)
         *reinterpret_cast<f4v*>(scratch + (lane & 15) * ep_row + (j * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
+      asm volatile("" ::: "memory");  // ... and this row's reads behind its writes
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = q * 4 + (lane >> 4);
         const f4v v = *reinterpret_cast<const f4v*>(scratch + row * ep_row + (lane & 15) * 16);
-        epi_apply_t<MODE, F0, F1>(a.e, a.M, z, m_base + i * 16 + row, n, make_float4(v.x, v.y, v.z, v.w), p0[c][ii][q],
-                                  p1[c][ii][q], bias);
+        if (!NGUARD || n_ok)
+          epi_apply_t<MODE, F0, F1>(a.e, a.M, z, m_base + i * 16 + row, n, make_float4(v.x, v.y, v.z, v.w), p0[c][ii][q],
+                                    p1[c][ii][q], bias);
       }
+      asm volatile("" ::: "memory");  // the next fragment row's LDS writes stay behind this row's reads
     }
   }
 }
@@ -429,10 +433,15 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) void gemm_bf16_k
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
   if (n_ok && a.e.bias && (a.e.mode == MI_EPI_BIAS_ACT || a.e.mode == MI_EPI_CROSS_FWD))
     bias = *reinterpret_cast<const float4*>(a.e.bias + n);
-  if (m0 + BM <= a.M && n0 + BN <= a.N) {  // uniform over the workgroup
+  if (m0 + BM <= a.M) {  // uniform over the workgroup: all rows inside
     const int64_t mb = m0 + (int64_t) wr * FM * 16;
     const mi_gemm_epilogue& e = a.e;
-#define EPI(MODE, F0, F1) epilogue_interior<MODE, F0, F1, FM, FN>(a, acc, scratch, EP_ROW, mb, n, z, lane, bias)
+    const bool n_edge = n0 + BN > a.N;
+#define EPI(MODE, F0, F1)                                                                                          \
+  do {                                                                                                             \
+    if (n_edge) epilogue_interior<MODE, F0, F1, true, FM, FN>(a, acc, scratch, EP_ROW, mb, n, n_ok, z, lane, bias); \
+    else epilogue_interior<MODE, F0, F1, false, FM, FN>(a, acc, scratch, EP_ROW, mb, n, n_ok, z, lane, bias);      \
+  } while (0)
     switch (e.mode) {
       case MI_EPI_SLAB: EPI(MI_EPI_SLAB, false, false); break;
       case MI_EPI_BIAS_ACT:
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) void gemm_bf16_k
 #undef EPI
     return;
   }
-  // a tile on the matrix's edge: every position checked, mode looked up per element
+  // a tile hanging over the last row: every position checked, mode looked up per element
   constexpr int CH = 4;
   static_assert(FM % CH == 0, "wave tile");
 #pragma unroll
