@@ -340,6 +340,12 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) void gemm_bf16_k
   const int64_t kend = kbeg + a.k_per_split < a.K ? kbeg + a.k_per_split : a.K;
   const int ktiles = (int) ((kend - kbeg) / BK);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w / WN, wc = w % WN;
+  // the epilogue's bias is requested now: a load issued at the end would be one more round trip per tile
+  const int64_t n = n0 + wc * FN * 16 + (lane & 15) * 4;
+  const bool n_ok = n < a.N;
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n_ok && a.e.bias && (a.e.mode == MI_EPI_BIAS_ACT || a.e.mode == MI_EPI_CROSS_FWD))
+    bias = *reinterpret_cast<const float4*>(a.e.bias + n);
 
   f4v acc[FM][FN];
 #pragma unroll
@@ -428,11 +434,6 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) void gemm_bf16_k
   constexpr int EP_ROW = 64 * 4 + 16;  // bytes of one row of 64 floats, padded against bank conflicts
   __builtin_amdgcn_s_barrier();        // every wave is done with the staging buffers
   char* const scratch = smem + w * (16 * EP_ROW);
-  const int64_t n = n0 + wc * FN * 16 + (lane & 15) * 4;
-  const bool n_ok = n < a.N;
-  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (n_ok && a.e.bias && (a.e.mode == MI_EPI_BIAS_ACT || a.e.mode == MI_EPI_CROSS_FWD))
-    bias = *reinterpret_cast<const float4*>(a.e.bias + n);
   if (m0 + BM <= a.M) {  // uniform over the workgroup: all rows inside
     const int64_t mb = m0 + (int64_t) wr * FM * 16;
     const mi_gemm_epilogue& e = a.e;
