@@ -20,15 +20,18 @@ __global__ __launch_bounds__(256) void pack_dense_kernel(const float* __restrict
   x[b * ld + col0 + j] = j < nd ? mi_f2bf(dense[b * nd + j]) : (unsigned short) 0;
 }
 
-// partial[s][n] = sum over rows of slice s of X[m][n].  Block = 64 column threads (8 columns each)
-// x 4 row lanes; a row lane walks rows lo+ty, lo+ty+4, ... with four loads in flight, the four
-// lanes are then added in lane order: a fixed order for a given (M, slices).
+// partial[s][n] = sum over rows of slice s of X[m][n].  Block = CT column threads (8 columns each)
+// x RL = 256/CT row lanes (CT = 64, or 16 for matrices of up to 128 columns, which would leave most
+// of 64 column threads idle); a row lane walks rows lo+ty, lo+ty+RL, ... with four loads in flight,
+// the lanes are then added in lane order: a fixed order for a given (M, N, slices).
+template <int CT>
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* __restrict__ X, int64_t ld, int64_t M,
                                                          int N, int rows_per_slice, float* __restrict__ partial,
                                                          int64_t ld_partial) {
-  __shared__ float sh[3][64][8];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int n = (blockIdx.x * 64 + tx) * 8;
+  constexpr int RL = 256 / CT;
+  __shared__ float sh[RL - 1][CT][8];
+  const int tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+  const int n = (blockIdx.x * CT + tx) * 8;
   const int s = blockIdx.y;
   const int64_t lo = (int64_t) s * rows_per_slice;
   const int64_t hi = lo + rows_per_slice < M ? lo + rows_per_slice : M;
@@ -38,11 +41,11 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* 
   if (n < N) {
     const bool wide = n + 8 <= N;  // N % 4 == 0: the last thread of a row may own only 4 columns
     int64_t m = lo + ty;
-    for (; m + 12 < hi; m += 16) {
+    for (; m + 3 * RL < hi; m += 4 * RL) {
       uint4 u[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const unsigned short* p = X + (m + 4 * j) * ld + n;
+        const unsigned short* p = X + (m + RL * j) * ld + n;
         if (wide) u[j] = *reinterpret_cast<const uint4*>(p);
         else { const uint2 h = *reinterpret_cast<const uint2*>(p); u[j] = make_uint4(h.x, h.y, 0u, 0u); }
       }
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* 
         acc[6] += __uint_as_float(u[j].w << 16); acc[7] += __uint_as_float(u[j].w & 0xFFFF0000u);
       }
     }
-    for (; m < hi; m += 4) {
+    for (; m < hi; m += RL) {
       const unsigned short* p = X + m * ld + n;
       uint4 u;
       if (wide) u = *reinterpret_cast<const uint4*>(p);
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* 
   __syncthreads();
   if (ty == 0 && n < N) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < RL - 1; ++t)
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] += sh[t][tx][k];
     float* out = partial + (int64_t) s * ld_partial + n;
@@ -381,8 +384,12 @@ extern "C" int mi_colsum_bf16(const void* X, int64_t ld, int64_t M, int N, int s
              "mi_colsum_bf16: bad arguments");
   MI_REQUIRE(ld % 8 == 0 && ((uintptr_t) X & 15) == 0, "mi_colsum_bf16: rows must be 16-byte aligned");
   const int rps = (int) mi_cdiv(M, slices);
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned) mi_cdiv(N, 512), (unsigned) slices), dim3(256), 0,
-                     (hipStream_t) stream, (const unsigned short*) X, ld, M, N, rps, partial, ld_partial);
+  if (N <= 128)
+    hipLaunchKernelGGL(colsum_bf16_kernel<16>, dim3(1, (unsigned) slices), dim3(256), 0, (hipStream_t) stream,
+                       (const unsigned short*) X, ld, M, N, rps, partial, ld_partial);
+  else
+    hipLaunchKernelGGL(colsum_bf16_kernel<64>, dim3((unsigned) mi_cdiv(N, 512), (unsigned) slices), dim3(256), 0,
+                       (hipStream_t) stream, (const unsigned short*) X, ld, M, N, rps, partial, ld_partial);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -64,7 +64,15 @@ __global__ __launch_bounds__(256) void linear_dw_final_kernel(const float* __res
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   float acc = 0.f;
-  for (int s = 0; s < splits; ++s) acc += partial[(int64_t) s * total + e];
+  int s = 0;
+  for (; s + 8 <= splits; s += 8) {  // eight loads in flight, added in slice order
+    float p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = partial[(int64_t) (s + j) * total + e];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += p[j];
+  }
+  for (; s < splits; ++s) acc += partial[(int64_t) s * total + e];
   if (e < K * N) dW[e] = acc;
   else if (db) db[e - K * N] = acc;
 }
