@@ -218,6 +218,17 @@ def _timed_steps(step, args):
     return time.perf_counter() - t0
 
 
+def _pmc_traffic(fname, workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC measurement of this same
+    workload (the counters cannot be collected from inside this process); None for any other."""
+    path = os.path.join(ROOT, 'profiles', fname)
+    if not os.path.exists(path):
+        return None
+    pmc = json.load(open(path))
+    k = pmc.get('kernels', {}).get(kernel)
+    return k['hbm_bytes_per_launch'] if k and pmc.get('workload') == workload else None
+
+
 def _line(args, workload, B, dt, dtype, config):
     return {'metric': 'train_samples_per_sec', 'value': round(B * args.steps / dt, 1), 'unit': 'samples/s', 'n_gpus': 1,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
@@ -253,7 +264,9 @@ def bench_dcn(args):
     flops = 2.0 * B * W.shape[0] * W.shape[1]
     res['roofline'] = {'kernel': 'gemm_bf16_kernel (MLP layer %dx%d forward, M=%d)' % (W.shape[0], W.shape[1], B),
                        'bound': 'mfma', 'achieved': round(flops / ms / 1e9, 1), 'peak': MFMA_PEAK_TFLOPS,
-                       'unit': 'TFLOP/s', 'frac': round(flops / ms / 1e9 / MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                       'unit': 'TFLOP/s', 'frac': round(flops / ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
+                       'traffic': _pmc_traffic('r01_dcn_b65536_pmc.json', res['config']['workload'],
+                                               'gemm_bf16_kernel fwd 1024x1024 M=65536'),
                        'alg_flops_per_launch': flops, 'ms_per_launch': round(ms, 5)}
     if not args.no_cpu_baseline:
         from oracle import dcn as odcn
@@ -316,7 +329,8 @@ def bench_din(args):
     nbytes = live * 64 * 4 + B * L * ib + B * L * 4 * 64 * 2 + B * (L + 1) * 4   # live rows + ids + A rows + index list
     res['roofline'] = {'kernel': 'din_build_kernel (gather + [q|k|q-k|q*k] rows)', 'bound': 'hbm',
                        'achieved': round(nbytes / ms / 1e6, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                       'frac': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), 'traffic': None,
+                       'frac': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                       'traffic': _pmc_traffic('r01_din_b8192_pmc.json', res['config']['workload'], 'din_build_kernel'),
                        'alg_bytes_per_launch': nbytes, 'ms_per_launch': round(ms, 5)}
     if not args.no_cpu_baseline:
         from oracle import din as odin
