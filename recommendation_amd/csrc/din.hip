@@ -70,12 +70,27 @@ __global__ __launch_bounds__(256) void din_pool_kernel(const unsigned short* __r
   if (b >= B) return;
   const int c = threadIdx.x & 15;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j = 0; j < L; ++j) {
-    if (ids_all[b * (L + 1) + j] < 0) continue;
-    const float w = a[b * L + j];
-    const ushort4 u = *reinterpret_cast<const ushort4*>(A + (b * L + j) * (4 * D) + D + c * 4);
-    acc.x = fmaf(w, mi_bf2f(u.x), acc.x); acc.y = fmaf(w, mi_bf2f(u.y), acc.y);
-    acc.z = fmaf(w, mi_bf2f(u.z), acc.z); acc.w = fmaf(w, mi_bf2f(u.w), acc.w);
+  // eight positions' loads in flight at a time (a walk position by position is a chain of L round
+  // trips); the terms are still added in ascending position order
+  for (int j0 = 0; j0 < L; j0 += 8) {
+    float w[8];
+    ushort4 u[8];
+    bool on[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int j = j0 + t;
+      on[t] = j < L && ids_all[b * (L + 1) + (j < L ? j : 0)] >= 0;
+      const int64_t at = b * L + (j < L ? j : 0);
+      w[t] = a[at];
+      u[t] = *reinterpret_cast<const ushort4*>(A + at * (4 * D) + D + c * 4);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (on[t]) {
+        acc.x = fmaf(w[t], mi_bf2f(u[t].x), acc.x); acc.y = fmaf(w[t], mi_bf2f(u[t].y), acc.y);
+        acc.z = fmaf(w[t], mi_bf2f(u[t].z), acc.z); acc.w = fmaf(w[t], mi_bf2f(u[t].w), acc.w);
+      }
+    }
   }
   *reinterpret_cast<float4*>(pooled + b * ld + c * 4) = acc;
 }
