@@ -350,8 +350,9 @@ int mi_shard_owner_fwd_sort(const mi_fm_table* tab, int64_t local_rows, const in
 
 /* Requester: partials[N][B][dim+2] (one slab per owner, summed in rank order) + dense part +
  * bias -> one row per sample of what the other ranks need,
- *   X[b] = [ S (dim) | g = (sigmoid(logit)-y)*gscale | BCE loss row | dense[b] (n_dense) | 0.. ]
- * with ld floats per row (ld % 4 == 0, ld >= dim+2+n_dense).  logit may be NULL.  part_out (may be
+ *   X[b] = [ S (dim) | g = (sigmoid(logit)-y)*gscale | BCE loss row | 0.. ]
+ * with ld floats per row (ld % 4 == 0, ld >= dim+2; when ld >= dim+2+n_dense the dense features
+ * are stored behind the loss as well).  logit may be NULL.  part_out (may be
  * NULL): mi_shard_dense_part_floats(B, dim, n_dense) floats, one partial per workgroup of this
  * launch of the dense-side sums over its samples (sum g*dense[.][j], sum g, sum loss); placed right
  * behind the B rows of X it travels with them in the all-gather. */

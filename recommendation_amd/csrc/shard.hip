@@ -745,7 +745,8 @@ __global__ __launch_bounds__(TS_THREADS) void owner_fwd_sort_kernel(OwnerArgs a,
 
 // Requester side: sum the owners' partials in rank order, add the dense part and the bias, and
 // write one row per sample of what the other ranks need:
-//   X[b] = [ S (DIM) | dL/dlogit | BCE loss row | dense features (n_dense) | padding ]   (ld floats)
+//   X[b] = [ S (DIM) | dL/dlogit | BCE loss row | padding ]   (ld floats; with ld >= DIM+2+n_dense the
+//          dense features follow the loss, for callers that want the whole sample in one row)
 // so that a single all-gather of X feeds every owner's backward and every replica's dense step.
 template <int DIM>
 __global__ __launch_bounds__(256) void fm_combine_kernel(const float* __restrict__ partials, int N, int B,
@@ -772,12 +773,13 @@ __global__ __launch_bounds__(256) void fm_combine_kernel(const float* __restrict
   float* x = X + (size_t) b * ld;
   *reinterpret_cast<float4*>(x + c * 4) = s;
   float ss = s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+  const bool keep_dense = ld >= DIM + 2 + n_dense;
   for (int j = c; j < n_dense; j += CH) {
     const float d = dense[(size_t) b * n_dense + j];
-    x[DIM + 2 + j] = d;
+    if (keep_dense) x[DIM + 2 + j] = d;
     lin = fmaf(wd[j], d, lin);
   }
-  for (int j = DIM + 2 + n_dense + c; j < ld; j += CH) x[j] = 0.f;
+  for (int j = DIM + 2 + (keep_dense ? n_dense : 0) + c; j < ld; j += CH) x[j] = 0.f;
 #pragma unroll
   for (int o = 1; o < CH; o <<= 1) {
     ss += __shfl_xor(ss, o, 64);
@@ -907,8 +909,8 @@ extern "C" int mi_fm_combine(const float* partials, int n_ranks, int64_t B, int 
   MI_REQUIRE(n_dense + 2 <= 256, "mi_fm_combine: at most 254 dense features");
   MI_REQUIRE(partials && X && n_ranks >= 1 && B >= 1, "mi_fm_combine: bad arguments");
   MI_REQUIRE(n_dense == 0 || (dense && wd), "mi_fm_combine: dense features need dense and wd");
-  MI_REQUIRE(ld >= dim + 2 + n_dense && ld % 4 == 0 && ((uintptr_t) X & 15) == 0,
-             "mi_fm_combine: X rows need ld >= dim+2+n_dense, ld %% 4 == 0, 16-byte alignment");
+  MI_REQUIRE(ld >= dim + 2 && ld % 4 == 0 && ((uintptr_t) X & 15) == 0,
+             "mi_fm_combine: X rows need ld >= dim+2, ld %% 4 == 0, 16-byte alignment");
   hipStream_t s = (hipStream_t) stream;
 #define CB_CASE(D)                                                                                                 \
   case D:                                                                                                          \

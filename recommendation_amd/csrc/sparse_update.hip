@@ -1064,7 +1064,7 @@ extern "C" int mi_shard_owner_bwd_dense(const mi_fm_table* tab, int64_t local_ro
   MI_REQUIRE(tab && sorted_rows && perm && n_total && X && dp && dm && dv && scratch && loss_out, "%s: null pointer",
              who);
   MI_REQUIRE(n_slots >= 0 && n_slots < ((int64_t) 1 << 31) && n_ranks >= 1 && B >= 1 && n_dense >= 0 &&
-                 n_dense + 2 <= FM_DENSE_THREADS && ld >= tab->dim + 2 + n_dense,
+                 n_dense + 2 <= FM_DENSE_THREADS && ld >= tab->dim + 2,
              "%s: bad n_slots/n_ranks/B/n_dense/ld", who);
   MI_REQUIRE(local_rows >= 1 && local_rows < (int64_t) 0x7FFFFFFFll, "%s: local_rows out of range", who);
   const int64_t part = mi_shard_dense_part_floats(B, tab->dim, n_dense);

@@ -476,8 +476,10 @@ def shard_block_ints(B, T):
     return -(-B // 64) * T + B * T
 
 
-def shard_row_floats(dim, n_dense):
-    """Floats per sample in the gathered rows [S | g | loss | dense | pad], a multiple of 4."""
+def shard_row_floats(dim, n_dense=0):
+    """Floats per sample in the gathered rows [S | g | loss | pad], a multiple of 4 (the dense side
+    travels as per-workgroup partial sums behind the sample rows; with n_dense the row also has
+    room for the dense features)."""
     return -(-(dim + 2 + n_dense) // 4) * 4
 
 

@@ -21,8 +21,8 @@ fixed size, and FOUR launches; nothing on the host ever waits for the device:
   B. all-to-all  [N][B][D+2] fp32     owner -> requester: per SAMPLE sum v, sum |v|^2, sum w1
                                       (not per (sample, field))
   launch 3  combine: sum the owners' partials in rank order, logit, loss, dL/dlogit -> X rows
-  C. all-gather  [B+e][D+2+nd] fp32   every sample's S, dL/dlogit, loss row and dense features, and
-                                      behind them the rank's dense-side partial sums
+  C. all-gather  [B+e][D+2 -> 20] fp32 every sample's S, dL/dlogit and loss row, and behind them the
+                                      rank's dense-side partial sums (the dense features stay home)
   launch 4  owner: sparse backward + fused optimizer | dense side: all ranks' partials added
 
 After C every owner has what its sparse backward needs and every replica adds the same dense-side
@@ -70,6 +70,10 @@ class HipBackend(object):
 
     def bwd_scratch(self, n_slots):
         return self.zeros((ops.shard_bwd_scratch_floats(n_slots),), torch.float32)
+
+    def row_floats(self):
+        """Floats per gathered sample row: S, dL/dlogit, loss (the dense features stay at home)."""
+        return ops.shard_row_floats(self.dim)
 
     def extra_rows(self, B, ld):
         """Rows behind the B sample rows of X that carry the combine launch's dense-side partials."""
@@ -174,7 +178,7 @@ class ShardedFactorizationMachine(object):
             return
         N, D, T, be = self.world, self.dim, self.T, self.be
         i32, f32 = torch.int32, torch.float32
-        self.ld = ops.shard_row_floats(D, self.n_dense)
+        self.ld = be.row_floats()
         blk = ops.shard_block_ints(B, T)
         self.send, self.recv = be.zeros((N, blk), i32), be.zeros((N, blk), i32)
         # room for every entry of every rank (an owner can receive them all)
