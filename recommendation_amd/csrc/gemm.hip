@@ -521,8 +521,6 @@ int dispatch_gemm(GemmArgs& g, int splits, hipStream_t s) {
   // transposing reads and 241 VGPRs lose, and narrow outputs do not fill its 256 columns.
   const int64_t big = mi_cdiv(g.M, 256) * mi_cdiv(g.N, 256) * splits;
   const bool fills = mi_cdiv(g.N, 256) * 256 * 100 <= g.N * 115;  // at most 15 % of the columns are padding
-  const char* force = getenv("MI_DBG_GEMM_TILE");  // TEMPORARY probe switch
-  if (force && force[0] == 's') return launch_gemm<A_TR, B_TR, 2, 2, 4, 4, 2>(g, splits, s);
   if (!A_TR && big >= 128 && fills && (!B_TR || g.N >= 512)) return launch_gemm<A_TR, B_TR, 2, 4, 8, 4, 2>(g, splits, s);
   return launch_gemm<A_TR, B_TR, 2, 2, 4, 4, 2>(g, splits, s);
 }
