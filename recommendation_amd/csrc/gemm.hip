@@ -514,8 +514,8 @@ int launch_gemm(GemmArgs& g, int splits, hipStream_t s) {
 template <bool A_TR, bool B_TR>
 int dispatch_gemm(GemmArgs& g, int splits, hipStream_t s) {
   // Two workgroup shapes (measured on the 65536-row shapes of a DCN-v2 step, TFLOP/s):
-  //   256x256, 8 waves x (128x64), 128 KiB LDS, 1 workgroup/CU:  forward 827-862, dX 435-536, dW 241-429
-  //   128x128, 4 waves x (64x64),   64 KiB LDS, 2 workgroups/CU: forward 719-757, dX 388-560, dW 652-695
+  //   256x256, 8 waves x (128x64), 128 KiB LDS, 1 workgroup/CU:  forward 1040-1100, masked dX 640-840, dW 241-429
+  //   128x128, 4 waves x (64x64),   64 KiB LDS, 2 workgroups/CU: forward and dX about 10 % below that, dW 650-730
   // The big tile halves the LDS and L2 bytes per flop and wins whenever the operands are read the
   // way they lie (ds_read_b128); with both operands reduction-major (weight gradients) its
   // transposing reads and 241 VGPRs lose, and narrow outputs do not fill its 256 columns.
