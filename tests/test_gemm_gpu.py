@@ -144,3 +144,43 @@ def test_transpose_bf16_bit_exact(dev, shape):
     dst = torch.zeros((C, R), dtype=torch.bfloat16, device=dev)
     ops.transpose_bf16(src, dst)
     assert torch.equal(dst, src.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,slices", [(4096, 1024, 64), (8200, 128, 256), (3000, 64, 7), (512, 448, 8)])
+def test_colsum_bf16_partials(dev, M, N, slices):
+    """Per-slice column sums of a bf16 matrix (both thread layouts: 64 column threads, and 16 for
+    matrices of up to 128 columns); small integers, so the fp32 sums are exact."""
+    from recommendation_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    X = torch.randint(-4, 5, (M, N), generator=g).to(torch.bfloat16).to(dev)
+    part = torch.full((slices, N), float('nan'), device=dev)
+    ops.colsum_bf16(X, slices, part)
+    rps = -(-M // slices)
+    want = torch.stack([X[s * rps:(s + 1) * rps].float().sum(0) for s in range(slices)])
+    assert torch.equal(part, want)
+
+
+@pytest.mark.parametrize("n,S", [(1024, 256), (516, 256), (128, 1024), (1024 * 1024, 8), (448, 3)])
+def test_slab_adam_sums_slabs_and_applies_tf_adam(dev, n, S):
+    """Both reductions (a thread walking all slabs of its four elements; 16 lanes sharing the slabs
+    of a short vector): integer slabs so the gradient is exact, then TensorFlow-form Adam."""
+    from recommendation_amd import ops
+    g = torch.Generator().manual_seed(n + S)
+    slab = torch.randint(-3, 4, (S, n), generator=g).float().to(dev)
+    w = torch.randn(n, generator=g).to(dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    w0 = w.clone()
+    grad = torch.empty(n, device=dev)
+    wb = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    lr_t, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-8
+    ops.slab_adam(slab, S, n, n, w, m, v, b1, b2, eps, lr_t=lr_t, w_bf16=wb, grad_out=grad)
+    gw = slab.sum(0)
+    assert torch.equal(grad, gw)
+    f32 = torch.float32
+    one = torch.tensor(1.0, dtype=f32)                       # (1 - beta) formed in fp32, as TensorFlow's kernel does
+    m_want = gw * (one - torch.tensor(b1, dtype=f32)).to(dev)
+    v_want = gw * gw * (one - torch.tensor(b2, dtype=f32)).to(dev)
+    w_want = w0 - (m_want * lr_t) / (v_want.sqrt() + eps)
+    assert torch.allclose(m, m_want, rtol=2e-6, atol=0) and torch.allclose(v, v_want, rtol=2e-6, atol=0)
+    assert torch.allclose(w, w_want, rtol=2e-6, atol=1e-7)
+    assert torch.equal(wb, w.to(torch.bfloat16))
