@@ -10,11 +10,13 @@
 // dim/VEC adjacent lanes, each owning VEC columns.  A serial loop over a run is a chain of
 // dependent loads (permutation entry -> gradient source), so a lane group sums only runs of up
 // to GROUP_MAX entries itself (all loads of a run issued together); a longer run of up to
-// WAVE_MAX entries is summed by the whole wave that met it,
-// and longer ones are queued to `long_list` for a second launch in which a workgroup strides
-// over the run.  Partial sums are combined in fixed trees, so hot rows (a table with three
-// rows gets a third of the batch each) neither serialise on four lanes nor change bits from
-// run to run.
+// WAVE_MAX entries is summed by the whole wave that met it, and longer ones by a workgroup: with
+// run arrays in the plan they are queued to `long_list` for a second launch; straight from
+// sorted_rows the workgroups of the same launch find them themselves, and a run of more than
+// SPLIT_MIN entries is summed piecewise by the workgroups of the chunks it spans (partials and
+// tickets in `long_list`).  Partial sums are combined in fixed trees and fixed position order, so
+// hot rows (a table with three rows gets a third of the batch each) neither serialise on four
+// lanes nor change bits from run to run.
 //
 // Runs come either from the compacted arrays of mi_embag_bwd_prepare (unique_rows /
 // seg_offsets) or, when the plan carries none, straight from sorted_rows: one wave per 64

@@ -1,5 +1,5 @@
 """The exchange logic of the row-wise sharded FM over torch.distributed, world_size 2 and 3, gloo,
-on CPU: local compute is the numpy stand-in, the five collectives are the real ones.  The result
+on CPU: local compute is the numpy stand-in, the three collectives of a step are the real ones.  The result
 must equal the single-process oracle FM trained on the concatenation of the ranks' batches."""
 import os
 import socket
