@@ -517,3 +517,31 @@ def test_fm_two_launch_step_equals_five_launch_step_bitwise(dev, opt, B):
     for m in models[1:]:
         assert torch.equal(models[0].table.rec, m.table.rec)
         assert torch.equal(models[0].dp, m.dp) and torch.equal(models[0].sched, m.sched)
+
+
+def test_piecewise_long_runs_exact_and_reproducible(dev):
+    """Runs far beyond 4096 entries (one-, two- and three-row tables at batch 32768) are summed in
+    pieces by several workgroups and combined by the last one to arrive: integer gradients make
+    every order give the same fp32 sum, so the result must equal the exact column sums, and it
+    must not change from call to call."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(21)
+    dim, B = 16, 32768
+    rows = [1, 2, 3, 50000]
+    T = len(rows)
+    toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    ids = np.stack([rng.integers(0, r, size=B) for r in rows], axis=1).astype(np.int64)     # [B][T]
+    grad = rng.integers(-3, 4, size=(B, T * dim)).astype(np.float32)
+    total = int(toffs[-1])
+    want = np.zeros((total, dim), np.float64)
+    for t in range(T):
+        np.add.at(want, toffs[t] + ids[:, t], grad[:, t * dim:(t + 1) * dim])
+    outs = []
+    for _ in range(3):
+        plan = ops.SortedPlan(torch.from_numpy(toffs).to(dev), T, total, torch.from_numpy(ids).to(dev), bag_len=1,
+                              runs=False)
+        w = torch.zeros((total, dim), device=dev)
+        ops.bwd_apply_sgd(plan, torch.from_numpy(grad).to(dev), w, -1.0)      # w = 0 + 1.0 * summed gradient
+        outs.append(w.cpu().numpy())
+    assert np.array_equal(outs[0], want.astype(np.float32))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
