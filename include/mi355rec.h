@@ -393,7 +393,10 @@ int mi_fm_dense_step_rows(const float* X, int ld, int dim, int n_dense, int64_t 
  * agreement with an fp32 evaluation is within 1e-2.
  * ---------------------------------------------------------------------------------- */
 #define MI_EPI_SLAB 0      /* out: fp32 [k_splits][M][ld_out] partial products (summed by mi_slab_adam) */
-#define MI_EPI_BIAS_ACT 1  /* out (bf16) = act(C + bias[n]); flags & MI_EPI_RELU */
+#define MI_EPI_BIAS_ACT 1  /* out (bf16) = act(C + bias[n]); flags & MI_EPI_RELU.  With bias_rows > 0 the
+                              bias is a matrix, one row per bias_rows consecutive rows of C:
+                              bias[(m / bias_rows) * bias_ld + n] (a term that only depends on the
+                              sample when C has one row per (sample, position)) */
 #define MI_EPI_CROSS_FWD 2 /* u = C + bias -> out1 (bf16, optional); out (bf16) = in0 * u + in1 */
 #define MI_EPI_MASK 3      /* out (bf16) = C where in0 > 0 else 0 (in0 NULL: plain store) */
 #define MI_EPI_CROSS_BWD 4 /* v = C + in1 (bf16, optional) -> out (bf16); with out1: out1 (bf16) = v * in0 */
@@ -410,6 +413,8 @@ typedef struct mi_gemm_epilogue {
   int64_t ld_in1;
   void* out1;
   int64_t ld_out1;
+  int64_t bias_ld; /* MI_EPI_BIAS_ACT with a bias matrix: floats between its rows, a multiple of 4 */
+  int bias_rows;   /* 0: bias is a vector */
 } mi_gemm_epilogue;
 
 /* C[m][n] = sum_k A(m,k)*B(n,k), followed by the epilogue.  An operand is stored either

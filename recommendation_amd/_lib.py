@@ -42,7 +42,7 @@ class GemmEpilogue(Structure):
     """struct mi_gemm_epilogue"""
     _fields_ = [('mode', c_int), ('flags', c_int), ('out', c_void_p), ('ld_out', c_int64), ('bias', c_void_p),
                 ('in0', c_void_p), ('ld_in0', c_int64), ('in1', c_void_p), ('ld_in1', c_int64),
-                ('out1', c_void_p), ('ld_out1', c_int64)]
+                ('out1', c_void_p), ('ld_out1', c_int64), ('bias_ld', c_int64), ('bias_rows', c_int)]
 
 
 P = c_void_p

@@ -167,6 +167,7 @@ __device__ __forceinline__ void epi_apply(const mi_gemm_epilogue& e, int64_t M, 
       break;
     }
     case MI_EPI_BIAS_ACT: {  // out = act(acc + bias)
+      if (e.bias_rows > 0) bias = *reinterpret_cast<const float4*>(e.bias + (m / e.bias_rows) * e.bias_ld + n);
       v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
       if (e.flags & MI_EPI_RELU) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -219,8 +220,12 @@ struct EpiInT {
   ushort4 p0, p1;
 };
 template <int MODE, bool F0, bool F1>
-__device__ __forceinline__ void epi_load_t(const mi_gemm_epilogue& e, int64_t m, int64_t n, ushort4& p0, ushort4& p1) {
-  if constexpr (MODE == MI_EPI_CROSS_FWD) {
+__device__ __forceinline__ void epi_load_t(const mi_gemm_epilogue& e, int64_t m, int64_t n, ushort4& p0, ushort4& p1,
+                                           float4& pb) {
+  if constexpr (MODE == MI_EPI_BIAS_ACT) {
+    // F1: the bias is a matrix with one row per bias_rows rows of C (m < 2^32 on this path: see the host check)
+    if constexpr (F1) pb = *reinterpret_cast<const float4*>(e.bias + (int64_t) ((uint32_t) m / (uint32_t) e.bias_rows) * e.bias_ld + n);
+  } else if constexpr (MODE == MI_EPI_CROSS_FWD) {
     p0 = ld_u4(e.in0, e.ld_in0, m, n);
     p1 = ld_u4(e.in1, e.ld_in1, m, n);
   } else if constexpr (MODE == MI_EPI_MASK) {
@@ -232,11 +237,12 @@ __device__ __forceinline__ void epi_load_t(const mi_gemm_epilogue& e, int64_t m,
 }
 template <int MODE, bool F0, bool F1>
 __device__ __forceinline__ void epi_apply_t(const mi_gemm_epilogue& e, int64_t M, int z, int64_t m, int64_t n, float4 v,
-                                            ushort4 p0, ushort4 p1, float4 bias) {
+                                            ushort4 p0, ushort4 p1, float4 pb, float4 bias) {
   if constexpr (MODE == MI_EPI_SLAB) {
     float* o = reinterpret_cast<float*>(e.out) + ((int64_t) z * M + m) * e.ld_out + n;
     *reinterpret_cast<float4*>(o) = v;
   } else if constexpr (MODE == MI_EPI_BIAS_ACT) {
+    if constexpr (F1) bias = pb;
     v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
     if constexpr (F0) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -278,13 +284,15 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& a, Acc& acc, c
   constexpr bool TWO_IN = MODE == MI_EPI_CROSS_FWD || (MODE == MI_EPI_CROSS_BWD && F0 && F1);
   constexpr int CH = TWO_IN ? 1 : 2, NCH = FM / CH;
   ushort4 p0[NCH][CH][4], p1[NCH][CH][4];
+  float4 pb[NCH][CH][4];
   auto load_chunk = [&](int c) {
 #pragma unroll
     for (int ii = 0; ii < CH; ++ii)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (!NGUARD || n_ok)  // NGUARD: the tile hangs over the last column; lanes beyond it only help with the transposes
-          epi_load_t<MODE, F0, F1>(a.e, m_base + (c * CH + ii) * 16 + q * 4 + (lane >> 4), n, p0[c][ii][q], p1[c][ii][q]);
+          epi_load_t<MODE, F0, F1>(a.e, m_base + (c * CH + ii) * 16 + q * 4 + (lane >> 4), n, p0[c][ii][q], p1[c][ii][q],
+                                   pb[c][ii][q]);
   };
   load_chunk(0);
 #pragma unroll
@@ -303,7 +311,7 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& a, Acc& acc, c
         const f4v v = *reinterpret_cast<const f4v*>(scratch + row * ep_row + (lane & 15) * 16);
         if (!NGUARD || n_ok)
           epi_apply_t<MODE, F0, F1>(a.e, a.M, z, m_base + i * 16 + row, n, make_float4(v.x, v.y, v.z, v.w), p0[c][ii][q],
-                                    p1[c][ii][q], bias);
+                                    p1[c][ii][q], pb[c][ii][q], bias);
       }
       asm volatile("" ::: "memory");  // the next fragment row's LDS writes stay behind this row's reads
     }
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) void gemm_bf16_k
   const int64_t n = n0 + wc * FN * 16 + (lane & 15) * 4;
   const bool n_ok = n < a.N;
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (n_ok && a.e.bias && (a.e.mode == MI_EPI_BIAS_ACT || a.e.mode == MI_EPI_CROSS_FWD))
+  if (n_ok && a.e.bias && ((a.e.mode == MI_EPI_BIAS_ACT && a.e.bias_rows <= 0) || a.e.mode == MI_EPI_CROSS_FWD))
     bias = *reinterpret_cast<const float4*>(a.e.bias + n);
 
   f4v acc[FM][FN];
@@ -446,7 +454,8 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) void gemm_bf16_k
     switch (e.mode) {
       case MI_EPI_SLAB: EPI(MI_EPI_SLAB, false, false); break;
       case MI_EPI_BIAS_ACT:
-        if (e.flags & MI_EPI_RELU) EPI(MI_EPI_BIAS_ACT, true, false); else EPI(MI_EPI_BIAS_ACT, false, false);
+        if (e.bias_rows > 0) { if (e.flags & MI_EPI_RELU) EPI(MI_EPI_BIAS_ACT, true, true); else EPI(MI_EPI_BIAS_ACT, false, true); }
+        else { if (e.flags & MI_EPI_RELU) EPI(MI_EPI_BIAS_ACT, true, false); else EPI(MI_EPI_BIAS_ACT, false, false); }
         break;
       case MI_EPI_CROSS_FWD:
         if (e.out1) EPI(MI_EPI_CROSS_FWD, true, false); else EPI(MI_EPI_CROSS_FWD, false, false);
@@ -550,6 +559,8 @@ extern "C" int mi_gemm_bf16(int a_reduction_major, int b_reduction_major, int64_
       break;
     case MI_EPI_BIAS_ACT:
       MI_REQUIRE(e.out && bf_ok(e.out, e.ld_out) && (!e.bias || al16p(e.bias)), "%s: bias/activation epilogue", who);
+      MI_REQUIRE(e.bias_rows == 0 || (e.bias && e.bias_rows > 0 && e.bias_ld % 4 == 0 && e.bias_ld >= N && M < ((int64_t) 1 << 32)),
+                 "%s: a bias matrix needs bias, bias_rows > 0, bias_ld %% 4 == 0, bias_ld >= N", who);
       break;
     case MI_EPI_CROSS_FWD:
       MI_REQUIRE(e.out && e.bias && e.in0 && e.in1 && al16p(e.bias) && bf_ok(e.out, e.ld_out) && bf_ok(e.out1, e.ld_out1) &&

@@ -552,7 +552,7 @@ def _ld(t):
 
 
 def gemm_bf16(A, B, mode, M=None, N=None, K=None, a_rm=False, b_rm=False, k_splits=1, flags=0, out=None, bias=None,
-              in0=None, in1=None, out1=None):
+              in0=None, in1=None, out1=None, bias_rows=0):
     """C[m][n] = sum_k A(m,k) B(n,k) on the matrix cores, then the epilogue ``mode`` (MI_EPI_*).
     A is [M][K] (or [K][M] with ``a_rm``), B is [N][K] (or [K][N] with ``b_rm``), both bf16 with
     contiguous rows; M, N, K default to the tensors' shapes (pass them to use a sub-block).  All
@@ -570,7 +570,8 @@ def gemm_bf16(A, B, mode, M=None, N=None, K=None, a_rm=False, b_rm=False, k_spli
         N = B.shape[1] if b_rm else B.shape[0]
     e = _lib.GemmEpilogue(mode=mode, flags=flags, out=_p(out), ld_out=out.stride(-2) if out is not None else 0,
                           bias=_p(bias), in0=_p(in0), ld_in0=_ld(in0), in1=_p(in1), ld_in1=_ld(in1),
-                          out1=_p(out1), ld_out1=_ld(out1))
+                          out1=_p(out1), ld_out1=_ld(out1), bias_ld=bias.stride(0) if bias_rows else 0,
+                          bias_rows=bias_rows)
     _lib.call('mi_gemm_bf16', int(a_rm), int(b_rm), M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), k_splits,
               ctypes.byref(e), _stream())
     return out

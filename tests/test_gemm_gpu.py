@@ -73,6 +73,20 @@ def test_bias_relu_epilogue(dev):
     assert ((out.float() - want).abs() <= want.abs() * 2 ** -8 + 1e-6).all()
 
 
+@pytest.mark.parametrize("M,N,K,rows", [(1200, 128, 128, 100), (512, 1024, 64, 8), (1000, 72, 192, 20)])
+def test_bias_matrix_epilogue(dev, M, N, K, rows):
+    """A bias that depends on the row group: bias[m // rows][n] (one bias row per sample when the
+    product has one row per (sample, position)); interior, last-column and last-row tiles."""
+    from recommendation_amd import ops
+    a, b, A, B = _operands(M, N, K, False, False, dev, seed=M, ints=False)
+    groups = -(-M // rows)
+    bias = torch.randn((groups, N + 4), device=dev)[:, :N]            # rows 16-byte aligned, not contiguous
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm_bf16(A, B, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=out, bias=bias, bias_rows=rows)
+    want = torch.relu(a.float() @ b.float().t() + bias.repeat_interleave(rows, dim=0)[:M])
+    assert ((out.float() - want).abs() <= want.abs() * 2 ** -8 + 1e-6).all()
+
+
 def test_cross_forward_epilogue(dev):
     from recommendation_amd import ops
     M, d = 384, 448
