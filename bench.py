@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument('--prefetch', action='store_true',
                     help='sharded path: route and exchange the ids of the next batch on a side stream beside this step\'s update '
                          '(measured slower at world size 1: the extra stream hops cost more than the exchange they hide)')
+    ap.add_argument('--din-full-rows', action='store_true',
+                    help='DIN: materialise the full [q | k | q-k | q*k] rows instead of the factored first layer')
     ap.add_argument('--force-sharded', action='store_true',
                     help='use the row-wise sharded model and its collectives even with one rank (rehearsal of the N > 1 path)')
     ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer'],
@@ -295,7 +297,7 @@ def bench_din(args):
     from recommendation_amd.din import DIN
     dev = torch.device('cuda', 0)
     B, L, rows = args.batch, 100, 1000000
-    m = DIN(rows, dev, max_len=L)
+    m = DIN(rows, dev, max_len=L, factored=not args.din_full_rows)
     g = torch.Generator(device=dev)
     g.manual_seed(1000)
     batches = []
@@ -326,11 +328,14 @@ def bench_din(args):
                     args.stage_reps)
     live = int(lens.sum().item())
     ib = args.idx_bits // 8
-    nbytes = live * 64 * 4 + B * L * ib + B * L * 4 * 64 * 2 + B * (L + 1) * 4   # live rows + ids + A rows + index list
-    res['roofline'] = {'kernel': 'din_build_kernel (gather + [q|k|q-k|q*k] rows)', 'bound': 'hbm',
+    nbytes = live * 64 * 4 + B * L * ib + B * L * m.A.shape[1] * 2 + B * (L + 1) * 4   # live rows + ids + A rows + index list
+    res['config']['first_layer'] = 'factored: rows [k | q*k], q term per sample' if m.factored else 'full rows [q | k | q-k | q*k]'
+    res['roofline'] = {'kernel': 'din_build_kernel (gather + %s rows)' % ('[k|q*k]' if m.factored else '[q|k|q-k|q*k]'),
+                       'bound': 'hbm',
                        'achieved': round(nbytes / ms / 1e6, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
-                       'traffic': _pmc_traffic('r01_din_b8192_pmc.json', res['config']['workload'], 'din_build_kernel'),
+                       'traffic': _pmc_traffic('r01_din_b8192_pmc.json', res['config']['workload'],
+                                               'din_build_kernel factored' if m.factored else 'din_build_kernel'),
                        'alg_bytes_per_launch': nbytes, 'ms_per_launch': round(ms, 5)}
     if not args.no_cpu_baseline:
         from oracle import din as odin

@@ -485,21 +485,22 @@ int mi_cross_input_grad(const void* const* dx, const void* const* u, int L, int6
  * mi_head_bwd / mi_gemm_bf16; these entry points do the memory-bound rest.
  * ---------------------------------------------------------------------------------- */
 
-/* Gather + build: A[B*L][4*dim] bf16 rows [q | k | q-k | q*k] (zero rows for positions
- * j >= len[b], negative ids, and ids >= rows - the latter also set MI_IDERR_RANGE), and
- * ids_all[B][L+1] int32 = the live history ids (else -1) followed by the candidate id: the index
- * list of the sparse backward.  q_out (optional) receives the fp32 candidate rows. */
+/* Gather + build: A[B*L][a_cols] bf16 rows, a_cols = 4*dim: [q | k | q-k | q*k], or a_cols = 2*dim:
+ * [k | q*k] (the factored unit below) - zero rows for positions j >= len[b], negative ids, and
+ * ids >= rows (the latter also set MI_IDERR_RANGE) - and ids_all[B][L+1] int32 = the live history
+ * ids (else -1) followed by the candidate id: the index list of the sparse backward.  q_out
+ * (optional) receives the fp32 candidate rows. */
 int mi_din_lau_build(const float* E, int64_t rows, int dim, const void* hist, const void* qid,
                      int idx_bits, const int32_t* len, int64_t B, int L, void* A, int32_t* ids_all,
-                     float* q_out, int64_t ld_q, int32_t* err, void* stream);
+                     float* q_out, int64_t ld_q, int a_cols, int32_t* err, void* stream);
 
 /* pooled[b][0..dim) = sum over live j (ascending) of a[b*L+j] * k_j, k_j taken from A. */
-int mi_din_lau_pool(const void* A, const float* a, const int32_t* ids_all, int64_t B, int L, int dim,
-                    float* pooled, int64_t ld, void* stream);
+int mi_din_lau_pool(const void* A, int a_cols, const float* a, const int32_t* ids_all, int64_t B,
+                    int L, int dim, float* pooled, int64_t ld, void* stream);
 
 /* da[b*L+j] = <dpooled[b], k_j> on live positions, 0 elsewhere. */
-int mi_din_lau_pool_bwd(const void* A, const float* dpooled, int64_t ld, const int32_t* ids_all,
-                        int64_t B, int L, int dim, float* da, void* stream);
+int mi_din_lau_pool_bwd(const void* A, int a_cols, const float* dpooled, int64_t ld,
+                        const int32_t* ids_all, int64_t B, int L, int dim, float* da, void* stream);
 
 /* dA[B*L][4*dim] (bf16) = gradient of the MLP's input rows.  Writes dE[B][L+1][dim] fp32, laid
  * out like ids_all:  d k_j = a_j*dpooled + dA_k - dA_d + q*dA_p;  d q = dq_extra (optional, what
@@ -507,6 +508,40 @@ int mi_din_lau_pool_bwd(const void* A, const float* dpooled, int64_t ld, const i
 int mi_din_lau_scatter(const void* A, const void* dA, const float* a, const float* dpooled,
                        int64_t ld_dp, const float* dq_extra, int64_t ld_dq, const int32_t* ids_all,
                        int64_t B, int L, int dim, float* dE, void* stream);
+
+/* The factored unit.  The first layer is linear in its input [q | k | q-k | q*k], so
+ *   A W1^T = q (Wa+Wc)^T + k (Wb-Wc)^T + (q*k) Wd^T          W1 = [Wa | Wb | Wc | Wd]
+ * and only [k | q*k] needs a row per (sample, position); the q term is one bias row per SAMPLE
+ * (mi_gemm_epilogue.bias_rows = L).  Same mathematics, half the bytes of the largest tensors.
+ *
+ * mi_din_lau_scatter_fact: A, dA are [B*L][2*dim] = [k | q*k], [gk | gp]; q fp32 [B][ld_q]:
+ *   d k_j = a_j*dpooled + gk + q*gp;   d q = dq_extra + sum_j k_j*gp, j ascending.
+ * mi_din_qterm_fwd: rowbias[B][H] fp32 = b1 + q Wq^T (Wq [H][dim] = Wa+Wc), the per-sample term.
+ * mi_din_qterm_bwd: from S[B][H] = per-sample sums of dZ (mi_colsum_bf16 with one slice per
+ *   sample): dq[b] = dq_in[b] (optional) + S[b] Wq, and per 64 samples a partial
+ *   part[chunk] = { (q^T S)[dim][H], sum_b S[b] (H) }  (mi_din_qterm_part_floats floats in all):
+ *   the gradient of Wa (transposed) and of b1, to be added in chunk order.
+ * mi_din_w1_step: TensorFlow-form Adam on the master W1 [H][4*dim] (m, v alike) from
+ *   slab[n_slabs][H][2*dim]  partial products of dZ^T [K | Q*K] (added in slab order) -> g_b, g_d
+ *   dWaT[n_a][dim][H] (rows a_stride floats apart) partials of q^T S, added in order  -> g_a
+ *   g_c = g_a - g_b
+ * and the tensors the next step reads: Wf [H][2*dim] bf16 = [Wb-Wc | Wd], WfT [2*dim][H] its
+ * transpose, Wq [H][dim] fp32 = Wa+Wc, WqT [dim][H].  grad_out (optional) [H][4*dim]. */
+int mi_din_lau_scatter_fact(const void* A, const void* dA, const float* a, const float* dpooled,
+                            int64_t ld_dp, const float* dq_extra, int64_t ld_dq, const float* q,
+                            int64_t ld_q, const int32_t* ids_all, int64_t B, int L, int dim,
+                            float* dE, void* stream);
+int64_t mi_din_qterm_part_floats(int64_t B, int H, int dim);
+int mi_din_qterm_fwd(const float* q, int64_t ld_q, const float* Wq, const float* b1, int64_t B, int H,
+                     int dim, float* rowbias, void* stream);
+int mi_din_qterm_bwd(const float* q, int64_t ld_q, const float* S, const float* Wq, int64_t B, int H,
+                     int dim, const float* dq_in, int64_t ld_in, float* dq, int64_t ld_dq,
+                     float* part, void* stream);
+int mi_din_w1_step(const float* slab, int n_slabs, int64_t slab_stride, const float* dWaT, int n_a,
+                   int64_t a_stride, int H, int dim, float* W, float* m, float* v, float lr_t,
+                   const float* lr_dev,
+                   float beta1, float beta2, float eps, void* Wf, void* WfT, float* Wq, float* WqT,
+                   float* grad_out, void* stream);
 
 /* BCE-with-logits on fp32 logits: loss rows and g = (sigmoid(z) - y) * gscale (either may be NULL). */
 int mi_bce_logits(const float* logits, const float* labels, int64_t B, float gscale,

@@ -8,7 +8,10 @@ recommendation/code/r_model.py:68-80).  This restates the unit of the DIN paper 
   pooled = sum_{j < len} a_j k_j                 (no softmax)
   logit  = Wh . [pooled | q] + bh,  BCE loss
 ``storage='bf16'`` rounds the tensors the device path stores in bfloat16 where it rounds them
-(see oracle/dcn.py for why gradients are compared that way).  Parity against the reference itself
+(see oracle/dcn.py for why gradients are compared that way).  ``factored=True`` evaluates the first
+layer as  q (Wa+Wc)^T + k (Wb-Wc)^T + (q*k) Wd^T  (W1 = [Wa | Wb | Wc | Wd]): the same function and
+the same gradients in exact arithmetic, but a different set of stored tensors ([k | q*k] rows,
+the combined weights), which is what the device's factored path rounds.  Parity against the reference itself
 is unpinned: there is nothing to compare with.
 """
 import numpy as np
@@ -50,7 +53,13 @@ def synthetic_batch(B, L, rows, seed=0):
     return hist, qid, lens, labels
 
 
-def forward(st, hist, qid, lens, dtype=np.float64, storage=None, keep=False):
+def _w1_blocks(st, dtype):
+    D = st.dim
+    W = st.W1.astype(dtype)
+    return W[:, :D], W[:, D:2 * D], W[:, 2 * D:3 * D], W[:, 3 * D:]
+
+
+def forward(st, hist, qid, lens, dtype=np.float64, storage=None, keep=False, factored=False):
     r = bf16_round if storage == 'bf16' else _keep
     hist, qid = np.asarray(hist, np.int64), np.asarray(qid, np.int64)
     B, L = hist.shape
@@ -59,11 +68,18 @@ def forward(st, hist, qid, lens, dtype=np.float64, storage=None, keep=False):
     q = st.E[qid].astype(dtype)
     k = st.E[np.where(mask, hist, 0)].astype(dtype) * mask[:, :, None]
     qb = np.broadcast_to(q[:, None, :], k.shape)
-    A = r(np.concatenate([qb, k, qb - k, qb * k], axis=2) * mask[:, :, None]).reshape(B * L, 4 * D)
-    H1 = r(np.maximum(A @ st.W1.T.astype(dtype) + st.b1.astype(dtype), 0))
+    if factored:
+        Wa, Wb, Wc, Wd = _w1_blocks(st, dtype)
+        A = r(np.concatenate([k, qb * k], axis=2) * mask[:, :, None]).reshape(B * L, 2 * D)
+        Wf = np.concatenate([r(Wb - Wc), r(Wd)], axis=1)              # the bf16 copy the contraction reads
+        rowbias = q @ (Wa + Wc).T + st.b1.astype(dtype)                # fp32 on the device, per sample
+        H1 = r(np.maximum(A @ Wf.T + np.repeat(rowbias, L, axis=0), 0))
+    else:
+        A = r(np.concatenate([qb, k, qb - k, qb * k], axis=2) * mask[:, :, None]).reshape(B * L, 4 * D)
+        H1 = r(np.maximum(A @ st.W1.T.astype(dtype) + st.b1.astype(dtype), 0))
     H2 = r(np.maximum(H1 @ st.W2.T.astype(dtype) + st.b2.astype(dtype), 0))
     a = (H2 @ st.w3.astype(dtype) + dtype(st.b3[0])).reshape(B, L)
-    kr = A[:, D:2 * D].reshape(B, L, D)                       # the k block as stored
+    kr = (A[:, :D] if factored else A[:, D:2 * D]).reshape(B, L, D)   # the k block as stored
     pooled = ((a * mask)[:, :, None] * kr).sum(1)
     feat = np.concatenate([pooled, q], axis=1)
     z = feat @ st.Wh.astype(dtype) + dtype(st.bh[0])
@@ -72,11 +88,11 @@ def forward(st, hist, qid, lens, dtype=np.float64, storage=None, keep=False):
     return z
 
 
-def grads(st, hist, qid, lens, labels, dtype=np.float64, storage=None):
+def grads(st, hist, qid, lens, labels, dtype=np.float64, storage=None, factored=False):
     """Mean BCE loss, gradients of the dense parameters by name, and of the item table as
     (unique rows, summed gradient rows)."""
     r = bf16_round if storage == 'bf16' else _keep
-    z, k = forward(st, hist, qid, lens, dtype, storage, keep=True)
+    z, k = forward(st, hist, qid, lens, dtype, storage, keep=True, factored=factored)
     hist, qid = np.asarray(hist, np.int64), np.asarray(qid, np.int64)
     B, L = hist.shape
     D = st.dim
@@ -94,14 +110,25 @@ def grads(st, hist, qid, lens, labels, dtype=np.float64, storage=None):
     out['lau/W2'] = dH2.T @ H1
     out['lau/b2'] = dH2.sum(0)
     dZ1 = r((dH2 @ st.W2.astype(dtype)) * (H1 > 0))
-    out['lau/W1'] = dZ1.T @ A
     out['lau/b1'] = dZ1.sum(0)
-    dA = r(dZ1 @ st.W1.astype(dtype)).reshape(B, L, 4 * D)
-    gq, gk, gd, gp = (dA[:, :, i * D:(i + 1) * D] for i in range(4))
-    qr = A[:, :D].reshape(B, L, D)
     m3 = mask[:, :, None]
-    dk = ((a * mask)[:, :, None] * dpooled[:, None, :] + gk - gd + qr * gp) * m3
-    dq += ((gq + gd + kr * gp) * m3).sum(1)
+    if factored:
+        Wa, Wb, Wc, Wd = _w1_blocks(st, dtype)
+        S = dZ1.reshape(B, L, -1).sum(1)                               # per-sample sums
+        gWa, gWf = S.T @ k['q'], dZ1.T @ A                             # gWf = [dZ^T K | dZ^T (Q*K)]
+        gWb, gWd = gWf[:, :D], gWf[:, D:]
+        out['lau/W1'] = np.concatenate([gWa, gWb, gWa - gWb, gWd], axis=1)
+        dA = r(dZ1 @ np.concatenate([r(Wb - Wc), r(Wd)], axis=1)).reshape(B, L, 2 * D)
+        gk, gp = dA[:, :, :D], dA[:, :, D:]
+        dk = ((a * mask)[:, :, None] * dpooled[:, None, :] + gk + k['q'][:, None, :] * gp) * m3
+        dq += (kr * gp * m3).sum(1) + S @ (Wa + Wc)
+    else:
+        out['lau/W1'] = dZ1.T @ A
+        dA = r(dZ1 @ st.W1.astype(dtype)).reshape(B, L, 4 * D)
+        gq, gk, gd, gp = (dA[:, :, i * D:(i + 1) * D] for i in range(4))
+        qr = A[:, :D].reshape(B, L, D)
+        dk = ((a * mask)[:, :, None] * dpooled[:, None, :] + gk - gd + qr * gp) * m3
+        dq += ((gq + gd + kr * gp) * m3).sum(1)
     rows = np.concatenate([np.where(mask, hist, -1), qid[:, None]], axis=1).reshape(-1)
     gr = np.concatenate([dk, dq[:, None, :]], axis=1).reshape(-1, D)
     live = rows >= 0
@@ -114,8 +141,8 @@ def grads(st, hist, qid, lens, labels, dtype=np.float64, storage=None):
 
 
 def train_step(st, hist, qid, lens, labels, lr=1e-3, emb_lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, emb_eps=1e-8,
-               dtype=np.float64, storage=None):
-    loss, gr, uniq, dE, _ = grads(st, hist, qid, lens, labels, dtype, storage)
+               dtype=np.float64, storage=None, factored=False):
+    loss, gr, uniq, dE, _ = grads(st, hist, qid, lens, labels, dtype, storage, factored)
     st.t += 1
     alpha, omb1, omb2 = emb.tf_adam_scalars(lr, beta1, beta2, st.t)
     for name, p in st.dense_params().items():

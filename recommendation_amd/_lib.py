@@ -89,9 +89,15 @@ _SIGNATURES = {
     'mi_cast_bf16': (c_int, [P, c_int64, P, P]),
     'mi_transpose_bf16': (c_int, [P, c_int64, c_int, c_int, P, c_int64, P]),
     'mi_cross_input_grad': (c_int, [P, P, c_int, c_int64, c_int, c_int64, P, c_int64, P]),
-    'mi_din_lau_build': (c_int, [P, c_int64, c_int, P, P, c_int, P, c_int64, c_int, P, P, P, c_int64, P, P]),
-    'mi_din_lau_pool': (c_int, [P, P, P, c_int64, c_int, c_int, P, c_int64, P]),
-    'mi_din_lau_pool_bwd': (c_int, [P, P, c_int64, P, c_int64, c_int, c_int, P, P]),
+    'mi_din_lau_build': (c_int, [P, c_int64, c_int, P, P, c_int, P, c_int64, c_int, P, P, P, c_int64, c_int, P, P]),
+    'mi_din_lau_pool': (c_int, [P, c_int, P, P, c_int64, c_int, c_int, P, c_int64, P]),
+    'mi_din_lau_pool_bwd': (c_int, [P, c_int, P, c_int64, P, c_int64, c_int, c_int, P, P]),
+    'mi_din_lau_scatter_fact': (c_int, [P, P, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int, c_int, P, P]),
+    'mi_din_qterm_part_floats': (c_int64, [c_int64, c_int, c_int]),
+    'mi_din_qterm_fwd': (c_int, [P, c_int64, P, P, c_int64, c_int, c_int, P, P]),
+    'mi_din_qterm_bwd': (c_int, [P, c_int64, P, P, c_int64, c_int, c_int, P, c_int64, P, c_int64, P, P]),
+    'mi_din_w1_step': (c_int, [P, c_int, c_int64, P, c_int, c_int64, c_int, c_int, P, P, P, c_float, P, c_float, c_float,
+                               c_float, P, P, P, P, P, P]),
     'mi_din_lau_scatter': (c_int, [P, P, P, P, c_int64, P, c_int64, P, c_int64, c_int, c_int, P, P]),
     'mi_bce_logits': (c_int, [P, P, c_int64, c_float, P, P, P]),
     'mi_fm_fwd_sort_max_batch': (c_int, []),

@@ -27,7 +27,7 @@ from .dcn import _Dense, _round_up
 
 class DIN(object):
     def __init__(self, rows, device, dim=64, h1=80, h2=40, max_len=100, lr=1e-3, emb_lr=1e-2, beta1=0.9,
-                 beta2=0.999, eps=1e-8, emb_eps=1e-8, seed=0, keep_grads=False):
+                 beta2=0.999, eps=1e-8, emb_eps=1e-8, seed=0, keep_grads=False, factored=False):
         if dim != 64:
             raise ValueError("DIN: only dim 64 is built")
         self.device = torch.device(device)
@@ -35,6 +35,8 @@ class DIN(object):
         self.h1p, self.h2p = _round_up(self.h1, 64), _round_up(self.h2, 64)
         self.lr, self.emb_lr, self.beta1, self.beta2, self.eps, self.emb_eps = lr, emb_lr, beta1, beta2, eps, emb_eps
         self.keep_grads = keep_grads
+        # factored: the first layer as q (Wa+Wc)^T + k (Wb-Wc)^T + (q*k) Wd^T, rows [k | q*k] only
+        self.factored = bool(factored)
         gen = torch.Generator(device='cpu')
         gen.manual_seed(seed)
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -65,6 +67,18 @@ class DIN(object):
         self.err = ops.new_error_word(self.device)
         self.steps = 0
         self._B = None
+        if self.factored:
+            self._derive_w1()
+
+    def _derive_w1(self):
+        """The tensors the factored first layer reads, from the master W1 = [Wa | Wb | Wc | Wd]
+        (after initialisation and load_state; a training step refreshes them in its weight-step kernel)."""
+        D = self.dim
+        Wa, Wb, Wc, Wd = (self.W1.w[:, i * D:(i + 1) * D] for i in range(4))
+        self.W1f = torch.cat([Wb - Wc, Wd], dim=1).to(torch.bfloat16).contiguous()
+        self.W1fT = self.W1f.t().contiguous()
+        self.Wq = (Wa + Wc).contiguous()
+        self.WqT = self.Wq.t().contiguous()
 
     def dense_params(self):
         return {'lau/W1': self.W1, 'lau/b1': self.b1, 'lau/W2': self.W2, 'lau/b2': self.b2, 'lau/w3b3': self.w3,
@@ -87,6 +101,8 @@ class DIN(object):
         self.w3.w[self.h2p] = float(st.b3[0])
         self.head.w[:2 * self.dim] = torch.from_numpy(st.Wh).to(dev)
         self.head.w[2 * self.dim] = float(st.bh[0])
+        if self.factored:
+            self._derive_w1()
 
     # -- buffers ------------------------------------------------------------------------------
     def _splits(self, n_out, k_in, M):
@@ -107,8 +123,15 @@ class DIN(object):
         dev = self.device
         bf = dict(dtype=torch.bfloat16, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
-        self.A = torch.empty((M, 4 * D), **bf)
-        self.dA = torch.empty((M, 4 * D), **bf)
+        ac = (2 if self.factored else 4) * D
+        self.A = torch.empty((M, ac), **bf)
+        self.dA = torch.empty((M, ac), **bf)
+        if self.factored:
+            self.rowbias = torch.empty((B, self.h1p), **f32)
+            self.S = torch.empty((B, self.h1p), **f32)            # per-sample sums of dZ1
+            self.dq = torch.empty((B, D), **f32)
+            self.qpart = torch.empty((ops.din_qterm_part_floats(B, self.h1p, D),), **f32)
+            self.gWf = torch.empty((self.h1p, 2 * D), **f32)
         self.H1, self.dZ1 = torch.empty((M, self.h1p), **bf), torch.empty((M, self.h1p), **bf)
         self.H2, self.dH2 = torch.empty((M, self.h2p), **bf), torch.empty((M, self.h2p), **bf)
         self.a, self.da = torch.empty((M,), **f32), torch.empty((M,), **f32)
@@ -117,7 +140,7 @@ class DIN(object):
         self.feat = torch.empty((B, 2 * D), **f32)            # [pooled | q]
         self.logit, self.loss_rows, self.g = (torch.empty((B,), **f32) for _ in range(3))
         self.loss = torch.empty((1,), **f32)
-        self.split = {(self.h1p, 4 * D): self._splits(self.h1p, 4 * D, M),
+        self.split = {(self.h1p, ac): self._splits(self.h1p, ac, M),
                       (self.h2p, self.h1p): self._splits(self.h2p, self.h1p, M)}
         self.vec_slices = max(1, min(1024, M // 64))
         n_slab = max(max(s * k[0] * k[1] for k, s in self.split.items()), self.vec_slices * (self.h1p + 4))
@@ -135,7 +158,13 @@ class DIN(object):
         self._buffers(B, hist)
         D = self.dim
         ops.din_lau_build(self.E, hist, qid, lengths, self.A, self.ids_all, q_out=self.feat[:, D:], err=self.err)
-        ops.gemm_bf16(self.A, self.W1.h, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=self.H1, bias=self.b1.w)
+        if self.factored:
+            # the q term of the first layer, once per sample (fp32), enters as a bias row per L positions
+            ops.din_qterm_fwd(self.feat[:, D:], self.Wq, self.b1.w, self.rowbias)
+            ops.gemm_bf16(self.A, self.W1f, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=self.H1, bias=self.rowbias,
+                          bias_rows=L)
+        else:
+            ops.gemm_bf16(self.A, self.W1.h, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=self.H1, bias=self.b1.w)
         ops.gemm_bf16(self.H1, self.W2.h, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=self.H2, bias=self.b2.w)
         ops.head_fwd(self.H2, self.w3.w[:self.h2p], self.w3.w[self.h2p:self.h2p + 1], None, 0.0, self.a, None, None)
         ops.din_lau_pool(self.A, self.a, self.ids_all, D, self.feat)
@@ -184,11 +213,14 @@ class DIN(object):
         ops.gemm_bf16(self.dH2, self.W2.hT, ops.MI_EPI_MASK, out=self.dZ1, in0=self.H1)
         self._weight_step(self.W2, self.dH2, self.H1)
         self._bias_step(self.b2, self.dH2)
-        ops.gemm_bf16(self.dZ1, self.W1.hT, ops.MI_EPI_MASK, out=self.dA)
-        self._weight_step(self.W1, self.dZ1, self.A)
-        self._bias_step(self.b1, self.dZ1)
-        # embedding rows: per-position gradients, then sort by row + fixed-order sums + row-wise Adagrad
-        ops.din_lau_scatter(self.A, self.dA, self.a, dfeat, dfeat[:, D:], self.ids_all, D, self.dE)
+        if self.factored:
+            self._first_layer_backward_factored(B, dfeat)
+        else:
+            ops.gemm_bf16(self.dZ1, self.W1.hT, ops.MI_EPI_MASK, out=self.dA)
+            self._weight_step(self.W1, self.dZ1, self.A)
+            self._bias_step(self.b1, self.dZ1)
+            # embedding rows: per-position gradients, then sort by row + fixed-order sums + row-wise Adagrad
+            ops.din_lau_scatter(self.A, self.dA, self.a, dfeat, dfeat[:, D:], self.ids_all, D, self.dE)
         self.plan.prepare(self.ids_all.view(-1))
         ops.bwd_apply_adagrad_rowwise(self.plan, self.dE, self.E, self.E_acc, self.emb_lr, self.emb_eps, grad_ld=D)
         self.steps += 1
@@ -196,7 +228,29 @@ class DIN(object):
             ops.check_error_word(self.err, "DIN ids")
         return self.loss
 
+    def _first_layer_backward_factored(self, B, dfeat):
+        """dZ1 -> gradients of [k | q*k], of q, of b1 and of the four blocks of W1, then the fused
+        weight step; data gradients are formed with the weights as the forward saw them."""
+        D, H = self.dim, self.h1p
+        q = self.feat[:, D:]
+        # S[b] = sum of dZ1 over the sample's positions: the column sums with one slice per sample
+        ops.colsum_bf16(self.dZ1, B, self.S, N=H)
+        # d q += S Wq; per 64 samples a partial of q^T S (-> d Wa) and of the column sums of S (-> d b1)
+        ops.din_qterm_bwd(q, self.S, self.Wq, dfeat[:, D:], self.dq, self.qpart)
+        chunks, stride = -(-B // 64), D * H + H
+        ops.slab_adam(self.qpart[D * H:], chunks, H, stride, self.b1.w, self.b1.m, self.b1.v, self.beta1, self.beta2,
+                      self.eps, lr_dev=self.sched, grad_out=self.b1.grad if self.keep_grads else None)
+        ops.gemm_bf16(self.dZ1, self.W1fT, ops.MI_EPI_MASK, out=self.dA)
+        s = self.split[(H, 2 * D)]
+        ops.gemm_bf16(self.dZ1, self.A, ops.MI_EPI_SLAB, a_rm=True, b_rm=True, M=H, N=2 * D, K=self.dZ1.shape[0],
+                      k_splits=s, out=self.slab[:s * H * 2 * D].view(s, H, 2 * D))
+        ops.slab_adam(self.slab, s, H * 2 * D, H * 2 * D, None, None, None, 0.0, 0.0, 0.0, grad_out=self.gWf)   # slabs -> one
+        ops.din_w1_step(self.gWf, 1, H * 2 * D, self.qpart, chunks, stride, self.W1.w, self.W1.m, self.W1.v, self.beta1,
+                        self.beta2, self.eps, self.W1f, self.W1fT, self.Wq, self.WqT, lr_dev=self.sched,
+                        grad_out=self.W1.grad if self.keep_grads else None)
+        ops.din_lau_scatter_fact(self.A, self.dA, self.a, dfeat, self.dq, q, self.ids_all, D, self.dE)
+
     def flops_per_sample(self):
         """Multiply-adds x2 of the unit's contractions in one training step, per sample (padded widths)."""
-        per_item = 4 * self.dim * self.h1p + self.h1p * self.h2p + self.h2p
+        per_item = (2 if self.factored else 4) * self.dim * self.h1p + self.h1p * self.h2p + self.h2p
         return 3 * 2 * per_item * self.L

@@ -629,19 +629,55 @@ def transpose_bf16(src, dst):
 
 # ----------------------------------------------------------------------------- DIN local activation unit
 def din_lau_build(E, hist, qid, lengths, A, ids_all, q_out=None, err=None):
+    """A [B*L][4*dim] = [q | k | q-k | q*k], or [B*L][2*dim] = [k | q*k] (chosen by A's width)."""
     B, L = hist.shape
     _lib.call('mi_din_lau_build', _p(E), E.shape[0], E.shape[1], _p(hist), _p(qid), _idx_bits(hist), _p(lengths), B, L,
-              _p(A), _p(ids_all), _p(q_out), q_out.stride(0) if q_out is not None else 0, _p(err), _stream())
+              _p(A), _p(ids_all), _p(q_out), q_out.stride(0) if q_out is not None else 0, A.shape[1], _p(err), _stream())
 
 
 def din_lau_pool(A, a, ids_all, dim, pooled):
     B, L1 = ids_all.shape
-    _lib.call('mi_din_lau_pool', _p(A), _p(a), _p(ids_all), B, L1 - 1, dim, _p(pooled), pooled.stride(0), _stream())
+    _lib.call('mi_din_lau_pool', _p(A), A.shape[1], _p(a), _p(ids_all), B, L1 - 1, dim, _p(pooled), pooled.stride(0),
+              _stream())
 
 
 def din_lau_pool_bwd(A, dpooled, ids_all, dim, da):
     B, L1 = ids_all.shape
-    _lib.call('mi_din_lau_pool_bwd', _p(A), _p(dpooled), dpooled.stride(0), _p(ids_all), B, L1 - 1, dim, _p(da),
+    _lib.call('mi_din_lau_pool_bwd', _p(A), A.shape[1], _p(dpooled), dpooled.stride(0), _p(ids_all), B, L1 - 1, dim,
+              _p(da), _stream())
+
+
+def din_lau_scatter_fact(A, dA, a, dpooled, dq_extra, q, ids_all, dim, dE):
+    B, L1 = ids_all.shape
+    _lib.call('mi_din_lau_scatter_fact', _p(A), _p(dA), _p(a), _p(dpooled), dpooled.stride(0), _p(dq_extra),
+              dq_extra.stride(0) if dq_extra is not None else 0, _p(q), q.stride(0), _p(ids_all), B, L1 - 1, dim, _p(dE),
+              _stream())
+
+
+def din_qterm_part_floats(B, H, dim):
+    return int(_lib.load().mi_din_qterm_part_floats(B, H, dim))
+
+
+def din_qterm_fwd(q, Wq, b1, rowbias):
+    """rowbias [B][H] = b1 + q Wq^T, the per-sample term of the factored first layer."""
+    B, H = rowbias.shape
+    _lib.call('mi_din_qterm_fwd', _p(q), q.stride(0), _p(Wq), _p(b1), B, H, Wq.shape[1], _p(rowbias), _stream())
+
+
+def din_qterm_bwd(q, S, Wq, dq_in, dq, part):
+    """dq = dq_in + S Wq; part = per-64-sample partials of q^T S and of the column sums of S."""
+    B, H = S.shape
+    if part.numel() < din_qterm_part_floats(B, H, Wq.shape[1]):
+        raise MiError("din_qterm_bwd: part too small")
+    _lib.call('mi_din_qterm_bwd', _p(q), q.stride(0), _p(S), _p(Wq), B, H, Wq.shape[1], _p(dq_in),
+              dq_in.stride(0) if dq_in is not None else 0, _p(dq), dq.stride(0), _p(part), _stream())
+
+
+def din_w1_step(slab, n_slabs, slab_stride, dWaT, n_a, a_stride, W, m, v, beta1, beta2, eps, Wf, WfT, Wq, WqT, lr_t=0.0,
+                lr_dev=None, grad_out=None):
+    H = W.shape[0]
+    _lib.call('mi_din_w1_step', _p(slab), n_slabs, slab_stride, _p(dWaT), n_a, a_stride, H, W.shape[1] // 4, _p(W),
+              _p(m), _p(v), lr_t, _p(lr_dev), beta1, beta2, eps, _p(Wf), _p(WfT), _p(Wq), _p(WqT), _p(grad_out),
               _stream())
 
 

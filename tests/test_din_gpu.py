@@ -29,11 +29,15 @@ def _to(dev, *arrs):
     return [torch.from_numpy(a).to(dev) for a in arrs]
 
 
+FACTORED = pytest.mark.parametrize("factored", [False, True], ids=["full_rows", "factored"])
+
+
+@FACTORED
 @pytest.mark.parametrize("B,L", [(64, 100), (32, 20)])
-def test_forward(dev, B, L):
+def test_forward(dev, B, L, factored):
     from recommendation_amd.din import DIN
     st = _state(1)
-    m = DIN(ROWS, dev, max_len=L)
+    m = DIN(ROWS, dev, max_len=L, factored=factored)
     m.load_state(st)
     hist, qid, lens, labels = odin.synthetic_batch(B, L, ROWS, seed=2)
     hist[3, 1] = -1                                          # a padding id inside the live range
@@ -44,7 +48,7 @@ def test_forward(dev, B, L):
     ids_want = np.concatenate([np.where(k['mask'], hist, -1), qid[:, None]], axis=1).astype(np.int32)
     assert np.array_equal(m.ids_all.cpu().numpy(), ids_want)
     # A rows: gathered rows combined in fp32 and rounded once
-    A_want = odin.forward(st, hist, qid, lens, keep=True, storage='bf16', dtype=np.float32)[1]['A']
+    A_want = odin.forward(st, hist, qid, lens, keep=True, storage='bf16', dtype=np.float32, factored=factored)[1]['A']
     assert np.array_equal(m.A.float().cpu().numpy(), A_want)
     assert rel(m.a.cpu().numpy().reshape(B, L) * k['mask'], k['a'] * k['mask']) <= 1e-2
     assert rel(m.feat.cpu().numpy()[:, :64], k['pooled']) <= 1e-2
@@ -52,16 +56,17 @@ def test_forward(dev, B, L):
     assert rel(z.cpu().numpy(), want) <= 1e-2
 
 
-def test_gradients_and_update(dev):
+@FACTORED
+def test_gradients_and_update(dev, factored):
     from recommendation_amd.din import DIN
     B, L = 64, 100
     st = _state(3)
-    m = DIN(ROWS, dev, max_len=L, keep_grads=True)
+    m = DIN(ROWS, dev, max_len=L, keep_grads=True, factored=factored)
     m.load_state(st)
     hist, qid, lens, labels = odin.synthetic_batch(B, L, ROWS, seed=4)
     hist[:, :3] = hist[0, :3]                                # rows shared by every sample: long runs
     loss_exact = odin.grads(st, hist, qid, lens, labels)[0]
-    loss_want, gr, uniq, dE, k = odin.grads(st, hist, qid, lens, labels, storage='bf16')
+    loss_want, gr, uniq, dE, k = odin.grads(st, hist, qid, lens, labels, storage='bf16', factored=factored)
     assert abs(loss_want - loss_exact) <= 1e-2 * abs(loss_exact)
     E_before = m.E.clone()
     loss = m.train_step(*_to(dev, hist, qid, lens, labels), check_ids=True)
@@ -94,18 +99,19 @@ def test_gradients_and_update(dev):
     assert rel(summed[uniq], dE) <= 1e-2
 
 
-def test_training_follows_the_oracle(dev):
+@FACTORED
+def test_training_follows_the_oracle(dev, factored):
     from recommendation_amd.din import DIN
     B, L = 32, 20
     st = _state(5)
-    m = DIN(ROWS, dev, max_len=L)
+    m = DIN(ROWS, dev, max_len=L, factored=factored)
     m.load_state(st)
     hist, qid, lens, labels = odin.synthetic_batch(B, L, ROWS, seed=6)
     t = _to(dev, hist, qid, lens, labels)
     got, want = [], []
     for _ in range(6):
         got.append(float(m.train_step(*t).item()))
-        want.append(float(odin.train_step(st, hist, qid, lens, labels, storage='bf16')))
+        want.append(float(odin.train_step(st, hist, qid, lens, labels, storage='bf16', factored=factored)))
     assert want[-1] < want[0]
     assert np.allclose(got, want, rtol=1e-2)
 

@@ -59,3 +59,18 @@ def test_bf16_round_is_round_to_nearest_even():
     want = torch.from_numpy(a).to(torch.bfloat16).float().numpy()
     assert np.array_equal(odcn.bf16_round(a), want)
     assert odcn.bf16_round(a.astype(np.float64)).dtype == np.float64
+
+
+def test_din_factored_first_layer_is_the_same_function():
+    """q (Wa+Wc)^T + k (Wb-Wc)^T + (q*k) Wd^T == [q | k | q-k | q*k] W1^T: loss and every gradient agree
+    to rounding in exact arithmetic (the factored form only changes which tensors are stored)."""
+    from oracle import din as odin
+    st = odin.State(500, seed=1)
+    hist, qid, lens, labels = odin.synthetic_batch(16, 12, 500, seed=2)
+    hist[3, 1] = -1
+    l0, g0, u0, d0, _ = odin.grads(st, hist, qid, lens, labels)
+    l1, g1, u1, d1, _ = odin.grads(st, hist, qid, lens, labels, factored=True)
+    assert abs(l0 - l1) <= 1e-12
+    for k in g0:
+        assert np.abs(g0[k] - g1[k]).max() <= 1e-12 * max(1.0, np.abs(g0[k]).max())
+    assert np.array_equal(u0, u1) and np.abs(d0 - d1).max() <= 1e-12
