@@ -270,6 +270,8 @@ __global__ __launch_bounds__(256) void din_qterm_bwd_kernel(const float* __restr
   constexpr int D = 64;
   __shared__ float sq[QB_CHUNK][D];
   __shared__ float sS[QB_CHUNK][128];
+  __shared__ float sW[128][D];
+  for (int i = threadIdx.x; i < H * D; i += 256) sW[i / D][i % D] = Wq[i];
   const int64_t b0 = (int64_t) blockIdx.x * QB_CHUNK;
   const int nb = (int) (B - b0 < QB_CHUNK ? B - b0 : QB_CHUNK);
   for (int i = threadIdx.x; i < QB_CHUNK * D; i += 256) {
@@ -290,9 +292,14 @@ __global__ __launch_bounds__(256) void din_qterm_bwd_kernel(const float* __restr
       for (int t = 0; t < 16; ++t) acc[t] = dq_in ? dq_in[(b0 + r) * ld_in + j0 + t] : 0.f;
       for (int n = 0; n < H; ++n) {
         const float sv = sS[r][n];
-        const float* wr = Wq + (int64_t) n * D + j0;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) acc[t] = fmaf(sv, wr[t], acc[t]);
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const float4 wv = *reinterpret_cast<const float4*>(&sW[n][j0 + 4 * t4]);
+          acc[4 * t4] = fmaf(sv, wv.x, acc[4 * t4]);
+          acc[4 * t4 + 1] = fmaf(sv, wv.y, acc[4 * t4 + 1]);
+          acc[4 * t4 + 2] = fmaf(sv, wv.z, acc[4 * t4 + 2]);
+          acc[4 * t4 + 3] = fmaf(sv, wv.w, acc[4 * t4 + 3]);
+        }
       }
 #pragma unroll
       for (int t = 0; t < 16; ++t) dq[(b0 + r) * ld_dq + j0 + t] = acc[t];

@@ -132,6 +132,7 @@ class DIN(object):
             self.dq = torch.empty((B, D), **f32)
             self.qpart = torch.empty((ops.din_qterm_part_floats(B, self.h1p, D),), **f32)
             self.gWf = torch.empty((self.h1p, 2 * D), **f32)
+            self.gq = torch.empty((D * self.h1p + self.h1p,), **f32)   # q^T S (transposed d Wa), then d b1
         self.H1, self.dZ1 = torch.empty((M, self.h1p), **bf), torch.empty((M, self.h1p), **bf)
         self.H2, self.dH2 = torch.empty((M, self.h2p), **bf), torch.empty((M, self.h2p), **bf)
         self.a, self.da = torch.empty((M,), **f32), torch.empty((M,), **f32)
@@ -238,14 +239,15 @@ class DIN(object):
         # d q += S Wq; per 64 samples a partial of q^T S (-> d Wa) and of the column sums of S (-> d b1)
         ops.din_qterm_bwd(q, self.S, self.Wq, dfeat[:, D:], self.dq, self.qpart)
         chunks, stride = -(-B // 64), D * H + H
-        ops.slab_adam(self.qpart[D * H:], chunks, H, stride, self.b1.w, self.b1.m, self.b1.v, self.beta1, self.beta2,
-                      self.eps, lr_dev=self.sched, grad_out=self.b1.grad if self.keep_grads else None)
+        ops.slab_adam(self.qpart, chunks, stride, stride, None, None, None, 0.0, 0.0, 0.0, grad_out=self.gq)   # chunks -> one
+        ops.slab_adam(self.gq[D * H:], 1, H, H, self.b1.w, self.b1.m, self.b1.v, self.beta1, self.beta2, self.eps,
+                      lr_dev=self.sched, grad_out=self.b1.grad if self.keep_grads else None)
         ops.gemm_bf16(self.dZ1, self.W1fT, ops.MI_EPI_MASK, out=self.dA)
         s = self.split[(H, 2 * D)]
         ops.gemm_bf16(self.dZ1, self.A, ops.MI_EPI_SLAB, a_rm=True, b_rm=True, M=H, N=2 * D, K=self.dZ1.shape[0],
                       k_splits=s, out=self.slab[:s * H * 2 * D].view(s, H, 2 * D))
         ops.slab_adam(self.slab, s, H * 2 * D, H * 2 * D, None, None, None, 0.0, 0.0, 0.0, grad_out=self.gWf)   # slabs -> one
-        ops.din_w1_step(self.gWf, 1, H * 2 * D, self.qpart, chunks, stride, self.W1.w, self.W1.m, self.W1.v, self.beta1,
+        ops.din_w1_step(self.gWf, 1, H * 2 * D, self.gq, 1, stride, self.W1.w, self.W1.m, self.W1.v, self.beta1,
                         self.beta2, self.eps, self.W1f, self.W1fT, self.Wq, self.WqT, lr_dev=self.sched,
                         grad_out=self.W1.grad if self.keep_grads else None)
         ops.din_lau_scatter_fact(self.A, self.dA, self.a, dfeat, self.dq, q, self.ids_all, D, self.dE)
