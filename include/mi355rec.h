@@ -518,7 +518,7 @@ int mi_din_lau_scatter(const void* A, const void* dA, const float* a, const floa
  *   d k_j = a_j*dpooled + gk + q*gp;   d q = dq_extra + sum_j k_j*gp, j ascending.
  * mi_din_qterm_fwd: rowbias[B][H] fp32 = b1 + q Wq^T (Wq [H][dim] = Wa+Wc), the per-sample term.
  * mi_din_qterm_bwd: from S[B][H] = per-sample sums of dZ (mi_colsum_bf16 with one slice per
- *   sample): dq[b] = dq_in[b] (optional) + S[b] Wq, and per 64 samples a partial
+ *   sample): dq[b] = dq_in[b] (optional) + S[b] Wq, and per 32 samples a partial
  *   part[chunk] = { (q^T S)[dim][H], sum_b S[b] (H) }  (mi_din_qterm_part_floats floats in all):
  *   the gradient of Wa (transposed) and of b1, to be added in chunk order.
  * mi_din_w1_step: TensorFlow-form Adam on the master W1 [H][4*dim] (m, v alike) from

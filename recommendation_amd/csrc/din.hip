@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void din_qterm_fwd_kernel(const float* __restr
 //   dWaT[j][n] = sum_b q[b][j] S[b][n]   and   db1[n] = sum_b S[b][n]
 // as partials part[chunk][D*H + H] (samples in ascending order; the chunks are added in order by
 // the weight step / mi_slab_adam).
-constexpr int QB_CHUNK = 64;
+constexpr int QB_CHUNK = 32;
 __global__ __launch_bounds__(256) void din_qterm_bwd_kernel(const float* __restrict__ q, int64_t ld_q,
                                                            const float* __restrict__ S, const float* __restrict__ Wq,
                                                            int64_t B, int H, float* __restrict__ dq, int64_t ld_dq,
@@ -283,17 +283,18 @@ __global__ __launch_bounds__(256) void din_qterm_bwd_kernel(const float* __restr
     sS[r][c] = r < nb ? S[(b0 + r) * H + c] : 0.f;
   }
   __syncthreads();
-  // dq: thread (r = tid / 4, quarter) -> 16 columns j of sample r
+  // dq: TPS threads per sample, CPT columns j each
   {
-    const int r = threadIdx.x >> 2, j0 = (threadIdx.x & 3) * 16;
+    constexpr int TPS = 256 / QB_CHUNK, CPT = D / TPS;
+    const int r = threadIdx.x / TPS, j0 = (threadIdx.x % TPS) * CPT;
     if (r < nb) {
-      float acc[16];
+      float acc[CPT];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) acc[t] = dq_in ? dq_in[(b0 + r) * ld_in + j0 + t] : 0.f;
+      for (int t = 0; t < CPT; ++t) acc[t] = dq_in ? dq_in[(b0 + r) * ld_in + j0 + t] : 0.f;
       for (int n = 0; n < H; ++n) {
         const float sv = sS[r][n];
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
+        for (int t4 = 0; t4 < CPT / 4; ++t4) {
           const float4 wv = *reinterpret_cast<const float4*>(&sW[n][j0 + 4 * t4]);
           acc[4 * t4] = fmaf(sv, wv.x, acc[4 * t4]);
           acc[4 * t4 + 1] = fmaf(sv, wv.y, acc[4 * t4 + 1]);
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256) void din_qterm_bwd_kernel(const float* __restr
         }
       }
 #pragma unroll
-      for (int t = 0; t < 16; ++t) dq[(b0 + r) * ld_dq + j0 + t] = acc[t];
+      for (int t = 0; t < CPT; ++t) dq[(b0 + r) * ld_dq + j0 + t] = acc[t];
     }
   }
   // partial dWaT: thread owns (j = tid / 4, 32 columns n)

@@ -236,9 +236,10 @@ class DIN(object):
         q = self.feat[:, D:]
         # S[b] = sum of dZ1 over the sample's positions: the column sums with one slice per sample
         ops.colsum_bf16(self.dZ1, B, self.S, N=H)
-        # d q += S Wq; per 64 samples a partial of q^T S (-> d Wa) and of the column sums of S (-> d b1)
+        # d q += S Wq; per 32 samples a partial of q^T S (-> d Wa) and of the column sums of S (-> d b1)
         ops.din_qterm_bwd(q, self.S, self.Wq, dfeat[:, D:], self.dq, self.qpart)
-        chunks, stride = -(-B // 64), D * H + H
+        stride = D * H + H
+        chunks = self.qpart.numel() // stride
         ops.slab_adam(self.qpart, chunks, stride, stride, None, None, None, 0.0, 0.0, 0.0, grad_out=self.gq)   # chunks -> one
         ops.slab_adam(self.gq[D * H:], 1, H, H, self.b1.w, self.b1.m, self.b1.v, self.beta1, self.beta2, self.eps,
                       lr_dev=self.sched, grad_out=self.b1.grad if self.keep_grads else None)

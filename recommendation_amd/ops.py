@@ -665,7 +665,7 @@ def din_qterm_fwd(q, Wq, b1, rowbias):
 
 
 def din_qterm_bwd(q, S, Wq, dq_in, dq, part):
-    """dq = dq_in + S Wq; part = per-64-sample partials of q^T S and of the column sums of S."""
+    """dq = dq_in + S Wq; part = per-32-sample partials of q^T S and of the column sums of S."""
     B, H = S.shape
     if part.numel() < din_qterm_part_floats(B, H, Wq.shape[1]):
         raise MiError("din_qterm_bwd: part too small")
