@@ -297,7 +297,7 @@ def bench_din(args):
     from recommendation_amd.din import DIN
     dev = torch.device('cuda', 0)
     B, L, rows = args.batch, 100, 1000000
-    m = DIN(rows, dev, max_len=L, factored=not args.din_full_rows)
+    m = DIN(rows, dev, max_len=L, factored=False if args.din_full_rows else None)
     g = torch.Generator(device=dev)
     g.manual_seed(1000)
     batches = []

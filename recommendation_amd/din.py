@@ -16,6 +16,13 @@ Adam (recommendation/code/model_trainer.py:157), mi_din_lau_scatter back to per-
 of the embedding rows, then the same deterministic sort-by-row update as every other table here.
 Positions beyond a sample's length are computed (their rows of A are zero) but masked out of the
 pooled sum and of every gradient.
+
+``factored`` (the default for a first hidden width up to 128): the first layer is linear in A, so
+A W1^T = q (Wa+Wc)^T + k (Wb-Wc)^T + (q*k) Wd^T with W1 = [Wa | Wb | Wc | Wd].  Only [k | q*k] is
+then stored per (sample, position) - half the bytes of the two largest tensors of the step - and
+the q term is one bias row per sample (mi_din_qterm_fwd, mi_gemm_epilogue.bias_rows); its
+gradients come from the per-sample sums of dZ (mi_din_qterm_bwd) and mi_din_w1_step assembles
+d W1 = [S^T q | dZ^T K | S^T q - dZ^T K | dZ^T (Q*K)] for the Adam step on the master weights.
 """
 import math
 
@@ -27,7 +34,7 @@ from .dcn import _Dense, _round_up
 
 class DIN(object):
     def __init__(self, rows, device, dim=64, h1=80, h2=40, max_len=100, lr=1e-3, emb_lr=1e-2, beta1=0.9,
-                 beta2=0.999, eps=1e-8, emb_eps=1e-8, seed=0, keep_grads=False, factored=False):
+                 beta2=0.999, eps=1e-8, emb_eps=1e-8, seed=0, keep_grads=False, factored=None):
         if dim != 64:
             raise ValueError("DIN: only dim 64 is built")
         self.device = torch.device(device)
@@ -35,8 +42,9 @@ class DIN(object):
         self.h1p, self.h2p = _round_up(self.h1, 64), _round_up(self.h2, 64)
         self.lr, self.emb_lr, self.beta1, self.beta2, self.eps, self.emb_eps = lr, emb_lr, beta1, beta2, eps, emb_eps
         self.keep_grads = keep_grads
-        # factored: the first layer as q (Wa+Wc)^T + k (Wb-Wc)^T + (q*k) Wd^T, rows [k | q*k] only
-        self.factored = bool(factored)
+        # factored: the first layer as q (Wa+Wc)^T + k (Wb-Wc)^T + (q*k) Wd^T, rows [k | q*k] only (the
+        # default wherever its kernels are built: first hidden width up to 128)
+        self.factored = self.h1p <= 128 if factored is None else bool(factored)
         gen = torch.Generator(device='cpu')
         gen.manual_seed(seed)
         f32 = dict(dtype=torch.float32, device=self.device)
