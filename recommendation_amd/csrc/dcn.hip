@@ -214,34 +214,17 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned short* __r
   }
 }
 
-// dh[b][k] = g[b] * w[k] where h[b][k] > 0 (ReLU of the layer that produced h), else 0
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w,
-                                                      const unsigned short* __restrict__ h, int64_t ld_h, int K,
-                                                      int64_t B, unsigned short* __restrict__ dh, int64_t ld_dh) {
-  const int kq = K / 4;
-  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (i >= B * kq) return;
-  const int64_t b = i / kq;
-  const int k = (int) (i - b * kq) * 4;
-  const float gb = g[b];
-  const float4 ww = *reinterpret_cast<const float4*>(w + k);
-  const ushort4 hh = *reinterpret_cast<const ushort4*>(h + b * ld_h + k);
-  ushort4 o;
-  o.x = mi_bf2f(hh.x) > 0.f ? mi_f2bf(gb * ww.x) : (unsigned short) 0;
-  o.y = mi_bf2f(hh.y) > 0.f ? mi_f2bf(gb * ww.y) : (unsigned short) 0;
-  o.z = mi_bf2f(hh.z) > 0.f ? mi_f2bf(gb * ww.z) : (unsigned short) 0;
-  o.w = mi_bf2f(hh.w) > 0.f ? mi_f2bf(gb * ww.w) : (unsigned short) 0;
-  *reinterpret_cast<ushort4*>(dh + b * ld_dh + k) = o;
-}
-
 // partial[s][k] = sum over samples of slice s of g[b]*h[b][k] (k < K);  partial[s][K] = sum g[b].
 // Block = ct column threads (4 columns each; a power of two <= 64; the thread at k == K owns the
 // bias column) x 256/ct row lanes; a row lane walks rows lo+ty, lo+ty+rl, ...; lanes are then
-// added in lane order.
+// added in lane order.  With w and dh given the same pass also writes the data gradient
+// dh[b][k] = g[b]*w[k] where h[b][k] > 0, else 0 (h is read once for both).
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ g,
                                                         const unsigned short* __restrict__ h, int64_t ld, int K,
                                                         int64_t B, int rows_per_slice, int ct,
-                                                        float* __restrict__ partial, int64_t ld_partial) {
+                                                        float* __restrict__ partial, int64_t ld_partial,
+                                                        const float* __restrict__ w, unsigned short* __restrict__ dh,
+                                                        int64_t ld_dh) {
   __shared__ float sh[256][4];
   const int rl = 256 / ct;
   const int tx = threadIdx.x % ct, ty = threadIdx.x / ct;
@@ -251,6 +234,15 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
   const int64_t hi = lo + rows_per_slice < B ? lo + rows_per_slice : B;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (k < K) {
+    const float4 ww = dh ? *reinterpret_cast<const float4*>(w + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto put = [&](int64_t row, float gb, ushort4 u) {
+      ushort4 o;
+      o.x = mi_bf2f(u.x) > 0.f ? mi_f2bf(gb * ww.x) : (unsigned short) 0;
+      o.y = mi_bf2f(u.y) > 0.f ? mi_f2bf(gb * ww.y) : (unsigned short) 0;
+      o.z = mi_bf2f(u.z) > 0.f ? mi_f2bf(gb * ww.z) : (unsigned short) 0;
+      o.w = mi_bf2f(u.w) > 0.f ? mi_f2bf(gb * ww.w) : (unsigned short) 0;
+      *reinterpret_cast<ushort4*>(dh + row * ld_dh + k) = o;
+    };
     int64_t b = lo + ty;
     for (; b + 3 * (int64_t) rl < hi; b += 4 * (int64_t) rl) {
       ushort4 u[4];
@@ -265,12 +257,17 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
         acc.x = fmaf(gb[j], mi_bf2f(u[j].x), acc.x); acc.y = fmaf(gb[j], mi_bf2f(u[j].y), acc.y);
         acc.z = fmaf(gb[j], mi_bf2f(u[j].z), acc.z); acc.w = fmaf(gb[j], mi_bf2f(u[j].w), acc.w);
       }
+      if (dh) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) put(b + (int64_t) j * rl, gb[j], u[j]);
+      }
     }
     for (; b < hi; b += rl) {
       const float gb = g[b];
       const ushort4 u = *reinterpret_cast<const ushort4*>(h + b * ld + k);
       acc.x = fmaf(gb, mi_bf2f(u.x), acc.x); acc.y = fmaf(gb, mi_bf2f(u.y), acc.y);
       acc.z = fmaf(gb, mi_bf2f(u.z), acc.z); acc.w = fmaf(gb, mi_bf2f(u.w), acc.w);
+      if (dh) put(b, gb, u);
     }
   } else if (k == K) {
     for (int64_t b = lo + ty; b < hi; b += rl) acc.x += g[b];
@@ -431,13 +428,11 @@ extern "C" int mi_head_bwd(const float* g, const float* w, const void* h, int64_
                  slices >= 1 && slices <= 65535,
              "mi_head_bwd: bad arguments");
   hipStream_t s = (hipStream_t) stream;
-  hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned) mi_cdiv(B * (K / 4), 256)), dim3(256), 0, s, g, w,
-                     (const unsigned short*) h, ld_h, K, B, (unsigned short*) dh, ld_dh);
   const int rps = (int) mi_cdiv(B, slices);
   int ct = 1;
   while (ct < 64 && ct < K / 4 + 1) ct <<= 1;
   hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned) mi_cdiv(K / 4 + 1, ct), (unsigned) slices), dim3(256), 0, s, g,
-                     (const unsigned short*) h, ld_h, K, B, rps, ct, partial, ld_partial);
+                     (const unsigned short*) h, ld_h, K, B, rps, ct, partial, ld_partial, w, (unsigned short*) dh, ld_dh);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
