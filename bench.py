@@ -53,6 +53,8 @@ def parse_args():
                          '(measured slower at world size 1: the extra stream hops cost more than the exchange they hide)')
     ap.add_argument('--din-full-rows', action='store_true',
                     help='DIN: materialise the full [q | k | q-k | q*k] rows instead of the factored first layer')
+    ap.add_argument('--ids-sample-major', action='store_true',
+                    help='feed the single-GPU step ids as [B][T] only (default: also one [B] row per field)')
     ap.add_argument('--force-sharded', action='store_true',
                     help='use the row-wise sharded model and its collectives even with one rank (rehearsal of the N > 1 path)')
     ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer'],
@@ -123,7 +125,7 @@ def sharded_stage_report(m, batch, reps, idx_bits):
     return stages, n, U
 
 
-def stage_report(fm, batch, reps, idx_bits):
+def stage_report(fm, batch, reps, idx_bits, ids_tm=None):
     """Per-stage device time and ALGORITHMIC bytes of one FM step at this batch."""
     from recommendation_amd import ops
     from recommendation_amd.fm import _OPT
@@ -156,7 +158,7 @@ def stage_report(fm, batch, reps, idx_bits):
         # the two launches the step is made of (timed without advancing the schedule / with step size 0)
         add('launch 1: forward + per-table LDS sort',
             lambda: ops.fm_fwd_sort(fm.table, fm.toffs, ids, fm.plan, nd_arg, fm.wd if nd else None, fm.bias, labels,
-                                    1.0 / B, fm.err, out=fm.buf), fwd_bytes + sort_bytes, 1)
+                                    1.0 / B, fm.err, out=fm.buf, ids_tm=ids_tm), fwd_bytes + sort_bytes, 1)
         add('launch 2: sparse update (segmented sum + fused %s) + dense side' % fm.opt,
             lambda: ops.fm_bwd_apply_dense(fm.plan, fm.table, r['g'], r['S'], _OPT[fm.opt], 0.0, fm.beta1, fm.beta2,
                                            fm.eps, nd_arg, r['loss_rows'], fm.dp, fm.dm, fm.dv, fm.loss),
@@ -428,11 +430,15 @@ def main():
 
     use_graph = (not sharded) and not args.no_graph
     kw = {'graph': True} if use_graph else {}
+    # one id tensor per field, stored field after field ([T][B]): the layout the two-launch step sorts fastest
+    tms = [b[0].t().contiguous() for b in batches] if (not sharded and not args.ids_sample_major) else None
+    kws = [dict(kw, ids_tm=tms[j]) if tms else kw for j in range(len(batches))]
     for i in range(max(args.warmup, len(batches) if use_graph else 0)):   # every batch's graph captured before timing
-        model.train_step(*batches[i % len(batches)], **kw)
+        model.train_step(*batches[i % len(batches)], **kws[i % len(batches)])
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        kw = kws[i % len(batches)]
         if sharded and args.prefetch:   # the next batch's ids are routed and exchanged beside this step's update
             kw = {'next_ids': batches[(i + 1) % len(batches)][0]}
         model.train_step(*batches[i % len(batches)], **kw)
@@ -454,12 +460,13 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'fm_criteo_%dx%d_b%d' % (len(rows), args.dim, B), 'global_batch': B * world,
                        'tables': len(rows), 'total_rows': int(sum(rows)), 'dim': args.dim, 'n_dense': 13,
-                       'id_bits': args.idx_bits, 'ids': args.dist, 'optimizer': args.opt,
+                       'id_bits': args.idx_bits, 'ids': args.dist,
+                       'id_layout': 'field-major [T][B]' if tms else 'sample-major [B][T]', 'optimizer': args.opt,
                        'launch': 'hip graph replay' if use_graph else 'eager',
                        'parallelism': 'single' if not sharded else 'rowwise-sharded tables x%d + replicated dense' % world},
         }
     if not sharded:
-        stages, U = stage_report(model, batches[0], args.stage_reps, args.idx_bits)
+        stages, U = stage_report(model, batches[0], args.stage_reps, args.idx_bits, tms[0] if tms else None)
         hbm = [s for s in stages if s['name'].startswith(('fm_fwd', 'fm_bwd_apply'))]
         upd = [s for s in stages if s['name'].startswith('launch 2')]
         dom = upd[0] if upd else max(hbm, key=lambda s: s['ms'])

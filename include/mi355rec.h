@@ -285,14 +285,17 @@ int mi_fm_dense_step(const float* g, const float* dense, int n_dense, int64_t B,
  * when sched != NULL, mi_adam_schedule_step in ONE launch: the three need only the step's inputs,
  * so the launch lasts as long as the longest of them.  B <= mi_fm_fwd_sort_max_batch() (a table's
  * B entries are sorted in the LDS of one CU); sorted_rows[B*T], perm[B*T] as mi_embag_bwd_prepare
- * writes them.  Results are bit-identical to the separate calls. */
+ * writes them.  Results are bit-identical to the separate calls.  ids_table_major != 0: ids is
+ * [T][B], one contiguous array per field - how the reference feeds its features, one tensor per
+ * field (r_model.py:42-51) - instead of [B][T]; a table's ids are then read as whole lines by its
+ * sort workgroups (one line per id otherwise); perm keeps the positions b*T + t either way. */
 int mi_fm_fwd_sort_max_batch(void);
 int mi_fm_fwd_sort(const mi_fm_table* tab, const int64_t* table_offsets, int T, const void* ids,
                    int idx_bits, int64_t B, const float* dense, int n_dense, const float* wd,
                    const float* bias, const float* labels, float gscale, float* logit, float* S,
                    float* loss_rows, float* g, int32_t* err, int64_t total_rows,
                    uint32_t* sorted_rows, int32_t* perm, float* sched, float lr, float beta1,
-                   float beta2, void* stream);
+                   float beta2, int ids_table_major, void* stream);
 
 /* mi_fm_bwd_apply and mi_fm_dense_step in ONE launch (both start from g; neither needs the
  * other).  lr / lr_dev belong to the sparse side (optimizer `opt`), dense_lr_t / dense_lr_dev

@@ -102,7 +102,7 @@ _SIGNATURES = {
     'mi_bce_logits': (c_int, [P, P, c_int64, c_float, P, P, P]),
     'mi_fm_fwd_sort_max_batch': (c_int, []),
     'mi_fm_fwd_sort': (c_int, [POINTER(FmTable), P, c_int, P, c_int, c_int64, P, c_int, P, P, P, c_float, P, P, P, P,
-                               P, c_int64, P, P, P, c_float, c_float, c_float, P]),
+                               P, c_int64, P, P, P, c_float, c_float, c_float, c_int, P]),
     'mi_fm_bwd_apply_dense': (c_int, [POINTER(BwdPlan), POINTER(FmTable), P, P, c_int, c_float, P, c_float, c_float,
                                       c_float, P, c_int, P, P, P, P, c_float, P, P, P]),
     'mi_parse_records': (c_int, [c_char_p, c_int64, c_int, c_int, c_int64, P, P, POINTER(c_int64), POINTER(c_int64)]),

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(TS_THREADS) void fm_fwd_sort_kernel(FmFwdArgs a, in
   const int sort_blocks = a.T * parts;
   if ((int) blockIdx.x < sort_blocks) {
     table_sort_body<IDX>(blockIdx.x / parts, blockIdx.x % parts, parts, a.toffs, a.T, a.ids, 1, a.B, sentinel,
-                         sorted_rows, perm);
+                         sorted_rows, perm, a.ids_tm != 0);
     return;
   }
   if (sched && (int) blockIdx.x == sort_blocks && threadIdx.x == 0) adam_schedule_body(sched, lr, b1, b2);
@@ -154,7 +154,7 @@ extern "C" int mi_fm_fwd(const mi_fm_table* tab, const int64_t* table_offsets, i
   const int rc = check_fwd("mi_fm_fwd", tab, table_offsets, T, ids, idx_bits, B, dense, n_dense, wd, S);
   if (rc) return rc;
   const FmFwdArgs a{*tab, table_offsets, T, ids, (int) B, dense, n_dense, wd, bias, labels, gscale, logit, S, loss_rows,
-                    g, err};
+                    g, err, 0};
   hipStream_t s = (hipStream_t) stream;
   if (idx_bits == 32) return launch_fm<int32_t>(a, 0u, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, s);
   return launch_fm<int64_t>(a, 0u, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, s);
@@ -166,7 +166,8 @@ extern "C" int mi_fm_fwd_sort(const mi_fm_table* tab, const int64_t* table_offse
                               int idx_bits, int64_t B, const float* dense, int n_dense, const float* wd,
                               const float* bias, const float* labels, float gscale, float* logit, float* S,
                               float* loss_rows, float* g, int32_t* err, int64_t total_rows, uint32_t* sorted_rows,
-                              int32_t* perm, float* sched, float lr, float beta1, float beta2, void* stream) {
+                              int32_t* perm, float* sched, float lr, float beta1, float beta2, int ids_table_major,
+                              void* stream) {
   const char* who = "mi_fm_fwd_sort";
   const int rc = check_fwd(who, tab, table_offsets, T, ids, idx_bits, B, dense, n_dense, wd, S);
   if (rc) return rc;
@@ -181,7 +182,7 @@ extern "C" int mi_fm_fwd_sort(const mi_fm_table* tab, const int64_t* table_offse
     return MI_ERR_UNSUPPORTED;
   }
   const FmFwdArgs a{*tab, table_offsets, T, ids, (int) B, dense, n_dense, wd, bias, labels, gscale, logit, S, loss_rows,
-                    g, err};
+                    g, err, ids_table_major ? 1 : 0};
   hipStream_t s = (hipStream_t) stream;
   uint32_t* pv = reinterpret_cast<uint32_t*>(perm);
   if (idx_bits == 32) return launch_fm<int32_t>(a, (uint32_t) total_rows, sorted_rows, pv, sched, lr, beta1, beta2, s);

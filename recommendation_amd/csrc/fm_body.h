@@ -20,6 +20,7 @@ struct FmFwdArgs {
   float* loss_rows;
   float* g;
   int32_t* err;
+  int ids_tm;  // ids are stored table-major [T][B] (one array per field, as the reference feeds its features) instead of [B][T]
 };
 
 // Forward of the samples of virtual workgroup `vblock` of `nthreads` threads.
@@ -63,7 +64,7 @@ __device__ __forceinline__ void fm_fwd_body(const FmFwdArgs& a, int vblock, int 
       const int f = f0 + u * FP;
       const bool present = f < T;
       const int fs = present ? f : 0;
-      const int64_t id = mi_ld_id<IDX>(ids, (int64_t) gid * T + fs);
+      const int64_t id = mi_ld_id<IDX>(ids, a.ids_tm ? (int64_t) fs * B + gid : (int64_t) gid * T + fs);
       const int64_t base = toffs[fs];
       const int64_t rows = toffs[fs + 1] - base;
       ok[u] = present && id >= 0 && id < rows;  // FM has no padding id: every field carries one id

@@ -270,7 +270,7 @@ template <typename IDX>
 __device__ __forceinline__ void table_sort_body(int t, int part, int parts, const int64_t* __restrict__ toffs, int T,
                                                 const void* __restrict__ indices, int bag_len, int n,
                                                 uint32_t sentinel, uint32_t* __restrict__ sorted_rows,
-                                                uint32_t* __restrict__ perm) {
+                                                uint32_t* __restrict__ perm, bool ids_tm = false) {
   __shared__ TsLds L;
   auto& kbuf = L.kbuf;
   auto& vbuf = L.vbuf;
@@ -288,7 +288,9 @@ __device__ __forceinline__ void table_sort_body(int t, int part, int parts, cons
     if (e < n) {
       const int b = e / bag_len;
       const int p = (b * T + t) * bag_len + (e - b * bag_len);
-      const int64_t id = mi_ld_id<IDX>(indices, p);
+      // table-major ids (bag_len 1): the table's ids are one contiguous run, a full-line load per wave
+      // instead of one line per id
+      const int64_t id = mi_ld_id<IDX>(indices, ids_tm ? (int64_t) t * n + e : (int64_t) p);
       kbuf[first][e] = (id >= 0 && id < (int64_t) rows) ? (uint32_t) id : rows;
       vbuf[first][e] = (uint32_t) p;
     }

@@ -109,7 +109,7 @@ class FactorizationMachine(object):
         return ops.fm_fwd(self.table, self.toffs, ids, dense if self.n_dense else None,
                           self.wd if self.n_dense else None, self.bias, labels, 1.0 / B, self.err, out=buf)
 
-    def _step_body(self, ids, dense, labels, streams=None):
+    def _step_body(self, ids, dense, labels, streams=None, ids_tm=None):
         """The launches of one step.  With ``streams`` (two side streams, used under graph capture)
         the sort runs beside the forward - it only needs the ids - and the dense-side update beside
         the sparse one."""
@@ -121,7 +121,7 @@ class FactorizationMachine(object):
             r = ops.fm_fwd_sort(self.table, self.toffs, ids, self.plan, dense if self.n_dense else None,
                                 self.wd if self.n_dense else None, self.bias, labels, 1.0 / B, self.err,
                                 out=self._buffers(ids), sched=self.sched, lr=self.lr, beta1=self.beta1,
-                                beta2=self.beta2)
+                                beta2=self.beta2, ids_tm=ids_tm)
             ops.fm_bwd_apply_dense(self.plan, self.table, r['g'], r['S'], _OPT[self.opt], self.lr, self.beta1,
                                    self.beta2, self.eps, dense if self.n_dense else None, r['loss_rows'], self.dp,
                                    self.dm, self.dv, self.loss, lr_dev=self.sched if adam else None,
@@ -152,13 +152,17 @@ class FactorizationMachine(object):
         else:
             dense_side()
 
-    def train_step(self, ids, dense, labels, check_ids=False, graph=False):
+    def train_step(self, ids, dense, labels, check_ids=False, graph=False, ids_tm=None):
         """One pass of the hot path; returns the mean loss as a 1-element device tensor.
         ``graph=True`` replays a HIP graph of the step captured on first use for these input
-        buffers (the inputs must stay at the same addresses; their contents may change)."""
+        buffers (the inputs must stay at the same addresses; their contents may change).
+        ``ids_tm``: the same ids as a contiguous [T][B] tensor (one row per field, the way the
+        reference feeds one tensor per feature); the two-launch step then reads that layout, which
+        lets a table's sort load its ids as whole lines."""
         self._buffers(ids)
         if graph:
-            key = (ids.data_ptr(), dense.data_ptr(), labels.data_ptr(), ids.shape[0])
+            key = (ids.data_ptr(), dense.data_ptr(), labels.data_ptr(), ids.shape[0],
+                   ids_tm.data_ptr() if ids_tm is not None else 0)
             g = self._graphs.get(key)
             if g is None:
                 if self._side is None:
@@ -166,11 +170,11 @@ class FactorizationMachine(object):
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._step_body(ids, dense, labels, streams=self._side)
+                    self._step_body(ids, dense, labels, streams=self._side, ids_tm=ids_tm)
                 self._graphs[key] = g
             g.replay()
         else:
-            self._step_body(ids, dense, labels)
+            self._step_body(ids, dense, labels, ids_tm=ids_tm)
         self.steps += 1
         if check_ids:
             ops.check_error_word(self.err, "FM ids")

@@ -418,9 +418,10 @@ def fm_fwd_sort_max_batch():
 
 
 def fm_fwd_sort(table, toffs, ids, plan, dense=None, wd=None, bias=None, labels=None, gscale=1.0, err=None, out=None,
-                sched=None, lr=0.0, beta1=0.9, beta2=0.999):
+                sched=None, lr=0.0, beta1=0.9, beta2=0.999, ids_tm=None):
     """fm_fwd + the sort of ``plan`` (built without run arrays for ids of this shape) + one optimizer
-    schedule step (``sched``), one launch.  Returns what fm_fwd returns; ``plan`` is ready for the apply."""
+    schedule step (``sched``), one launch.  Returns what fm_fwd returns; ``plan`` is ready for the apply.
+    ``ids_tm``: the same ids table-major, [T][B] (one array per field); read instead of ``ids`` when given."""
     _need_cuda(table.rec, toffs, ids, dense, wd, bias, labels, err, sched)
     B, T = ids.shape
     if plan.runs or plan.n_entries != B * T or plan.bag_len != 1 or plan.T != T:
@@ -435,9 +436,14 @@ def fm_fwd_sort(table, toffs, ids, plan, dense=None, wd=None, bias=None, labels=
         g = buf['g'] if buf.get('g') is not None else torch.empty((B,), **f32)
     n_dense = dense.shape[1] if dense is not None else 0
     ids = ids.contiguous()
-    _lib.call('mi_fm_fwd_sort', table.ref(), _p(toffs), T, _p(ids), _idx_bits(ids), B, _p(dense), n_dense, _p(wd),
+    if ids_tm is not None:
+        _need_cuda(ids_tm)
+        if tuple(ids_tm.shape) != (T, B) or ids_tm.dtype != ids.dtype or not ids_tm.is_contiguous():
+            raise MiError("fm_fwd_sort: ids_tm must be the contiguous [T][B] transpose of ids")
+    src = ids if ids_tm is None else ids_tm
+    _lib.call('mi_fm_fwd_sort', table.ref(), _p(toffs), T, _p(src), _idx_bits(ids), B, _p(dense), n_dense, _p(wd),
               _p(bias), _p(labels), gscale, _p(logit), _p(S), _p(loss_rows), _p(g), _p(err), plan.total_rows,
-              _p(plan.sorted_rows), _p(plan.perm), _p(sched), lr, beta1, beta2, _stream())
+              _p(plan.sorted_rows), _p(plan.perm), _p(sched), lr, beta1, beta2, 0 if ids_tm is None else 1, _stream())
     return dict(logit=logit, S=S, loss_rows=loss_rows, g=g)
 
 

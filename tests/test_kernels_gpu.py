@@ -519,6 +519,42 @@ def test_fm_two_launch_step_equals_five_launch_step_bitwise(dev, opt, B):
         assert torch.equal(models[0].dp, m.dp) and torch.equal(models[0].sched, m.sched)
 
 
+@pytest.mark.parametrize("idt", ["int64", "int32"])
+@pytest.mark.parametrize("B", [700, 8192])
+def test_fm_field_major_ids_give_the_same_bits(dev, B, idt):
+    """The two-launch step fed the ids as one row per field ([T][B], the reference's one tensor per
+    feature, recommendation/code/r_model.py:42-51) must leave the bits of the [B][T] step: same
+    sorted rows, same permutation, same records, dense parameters and loss; eager and replayed."""
+    from recommendation_amd.fm import FactorizationMachine
+    rows = [1460, 583, 30000, 305, 24, 3, 10, 4, 18, 15, 105, 27, 2173]
+    ref = ofm.State(rows, 16, 13, seed=9, opt='adam_tf')
+    models = [FactorizationMachine(rows, 16, 13, device=dev, opt='adam_tf', lr=1e-2) for _ in range(3)]
+    for m in models:
+        m.load_state(ref)
+    bufs = tm = None
+    for step in range(3):
+        arrs = list(ofm.synthetic_batch(B, rows, 13, seed=70 + step, dist='zipf'))
+        arrs[0] = arrs[0].astype(idt)
+        if bufs is None:
+            bufs = tuple(torch.from_numpy(x).to(dev) for x in arrs)
+            tm = bufs[0].t().contiguous()
+        else:
+            for dst, src in zip(bufs, arrs):
+                dst.copy_(torch.from_numpy(src))
+            tm.copy_(bufs[0].t())
+        l0 = models[0].train_step(*bufs).clone()
+        l1 = models[1].train_step(*bufs, ids_tm=tm).clone()
+        l2 = models[2].train_step(*bufs, ids_tm=tm, graph=True).clone()
+        assert torch.equal(l0, l1) and torch.equal(l0, l2)
+        assert torch.equal(models[0].plan.sorted_rows, models[1].plan.sorted_rows)
+        assert torch.equal(models[0].plan.perm, models[1].plan.perm)
+    for m in models[1:]:
+        assert torch.equal(models[0].table.rec, m.table.rec)
+        assert torch.equal(models[0].dp, m.dp) and torch.equal(models[0].sched, m.sched)
+    with pytest.raises(RuntimeError):
+        models[1].train_step(*bufs, ids_tm=tm[:, :-1])
+
+
 def test_piecewise_long_runs_exact_and_reproducible(dev):
     """Runs far beyond 4096 entries (one-, two- and three-row tables at batch 32768) are summed in
     pieces by several workgroups and combined by the last one to arrive: integer gradients make
