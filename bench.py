@@ -57,7 +57,10 @@ def parse_args():
                     help='feed the single-GPU step ids as [B][T] only (default: also one [B] row per field)')
     ap.add_argument('--force-sharded', action='store_true',
                     help='use the row-wise sharded model and its collectives even with one rank (rehearsal of the N > 1 path)')
-    ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer'],
+    ap.add_argument('--bag-len', type=int, default=1, help='embag workload: ids per bag (sum pooling)')
+    ap.add_argument('--embag-rows', type=int, default=1000000000 // 8,
+                    help='embag workload: total rows over the 26 tables (default: one GPU\'s eighth of 1 G rows)')
+    ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer', 'embag'],
                     help='fm (default, the headline configuration); dcn / din: the bf16 matrix-core configurations, 1 GPU')
     return ap.parse_args()
 
@@ -293,6 +296,111 @@ def bench_dcn(args):
     return res
 
 
+def bench_embag(args):
+    """Embedding gather + sum pooling forward and the sort-based backward with the fused row-wise
+    Adagrad update, on one GPU's share of the sharded-table configuration: 26 tables, 125 M rows x
+    dim 128 fp32 (64 GB), batch 65536.  The upstream gradient is a fixed synthetic buffer."""
+    from recommendation_amd import ops
+    dev = torch.device('cuda', 0)
+    T, L = 26, args.bag_len
+    D = args.dim if args.dim != 16 else 128
+    B = args.batch if args.batch != 8192 else 65536
+    rows = [args.embag_rows // T] * T
+    total = sum(rows)
+    toffs = ops.table_offsets(rows, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000)
+    W = torch.empty((total, D), dtype=torch.float32, device=dev)
+    chunk = 1 << 22
+    for lo in range(0, total, chunk):
+        hi = min(lo + chunk, total)
+        W[lo:hi] = torch.randn((hi - lo, D), generator=g, dtype=torch.float32, device=dev).mul_(0.05)
+    state = torch.zeros((total,), dtype=torch.float32, device=dev)
+    card = torch.tensor(rows, dtype=torch.float64, device=dev).view(1, T, 1)
+    idt = torch.int64 if args.idx_bits == 64 else torch.int32
+    batches = []
+    for _ in range(4):
+        u = torch.rand((B, T, L), generator=g, dtype=torch.float64, device=dev)
+        if args.dist == 'zipf':
+            a = 1.0 - 1.05
+            ids = torch.floor(((u * ((card + 1.0) ** a - 1.0)) + 1.0) ** (1.0 / a)) - 1.0
+        else:
+            ids = torch.floor(u * card)
+        batches.append(torch.minimum(ids.clamp_(min=0), card - 1).to(idt).contiguous())
+    grad = torch.randn((B, T * D), generator=g, dtype=torch.float32, device=dev).mul_(1e-3)
+    out = torch.empty((B, T * D), dtype=torch.float32, device=dev)
+    err = ops.new_error_word(dev)
+    plan = ops.SortedPlan(toffs, T, total, batches[0], bag_len=L, runs=False)
+    it = [0]
+
+    def fwd(ids):
+        ops.embag_fwd(W, toffs, T, ids, bag_len=L, check_flags=ops.MI_CHECK_RANGE, err=err, out=out)
+
+    def upd():
+        ops.bwd_apply_adagrad_rowwise(plan, grad, W, state, 0.01, 1e-8)
+
+    def step():
+        ids = batches[it[0] % len(batches)]
+        fwd(ids)
+        plan.prepare(ids)
+        upd()
+        it[0] += 1
+
+    dt = _timed_steps(step, args)
+    ops.check_error_word(err, "bench ids")
+    n = B * T * L
+    ib = args.idx_bits // 8
+    res = _line(args, 'embag_26x%d_rows%dM_b%d_l%d' % (D, total // 1000000, B, L), B, dt, 'f32',
+                dict(tables=T, total_rows=total, dim=D, bag_len=L, pooling='sum', id_bits=args.idx_bits, ids=args.dist,
+                     table_bytes=total * D * 4, optimizer='adagrad_rowwise (fused into the sparse backward)'))
+    ids = batches[0]
+    plan.prepare(ids)
+    U = int(torch.unique(plan.sorted_rows[:n]).numel())
+    fwd_bytes = n * (D * 4 + ib) + B * T * D * 4
+    upd_bytes = n * 8 + (n if L == 1 else B * T) * D * 4 + U * (D * 4 + 4) * 2
+    stages = []
+    for name, fn, nb in (('embag_fwd (gather + sum pooling)', lambda: fwd(ids), fwd_bytes),
+                         ('sort_by_row', lambda: plan.prepare(ids), n * (ib + 8)),
+                         ('sparse backward + fused row-wise adagrad', upd, upd_bytes)):
+        ms = time_stage(fn, args.stage_reps)
+        stages.append(dict(name=name, ms=round(ms, 5), alg_bytes=int(nb), gbs=round(nb / ms / 1e6, 1)))
+    res['stages'] = stages
+    res['unique_rows_per_step'] = U
+    emb = [stages[0], stages[2]]
+    res['embedding_hbm_gbs'] = round(sum(s['alg_bytes'] for s in emb) / sum(s['ms'] for s in emb) / 1e6, 1)
+    dom = max(emb, key=lambda s: s['ms'])
+    kern = 'embag_fwd_kernel' if dom is stages[0] else 'seg_sorted_kernel'
+    res['roofline'] = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                       'frac': round(dom['gbs'] / HBM_PEAK_GBS, 4),
+                       'traffic': _pmc_traffic('r01_embag_b65536_pmc.json', res['config']['workload'], kern),
+                       'alg_bytes_per_launch': dom['alg_bytes'], 'ms_per_launch': dom['ms']}
+    if not args.no_cpu_baseline:
+        from oracle import embedding as oe
+        Bc, rc = 2048, 100000
+        rng = np.random.default_rng(0)
+        toffs_c = np.arange(T + 1, dtype=np.int64) * rc
+        Wc = (rng.standard_normal((T * rc, D)) * 0.05).astype(np.float32)
+        stc = np.zeros(T * rc, np.float32)
+        idc = rng.integers(0, rc, size=(Bc, T, L)).astype(np.int64)
+        gc = (rng.standard_normal((Bc, T * D)) * 1e-3).astype(np.float32)
+
+        def cpu_step():
+            oe.embag_fwd(Wc, toffs_c, T, idc, bag_len=L)
+            oe.apply_adagrad_rowwise(Wc, stc, oe.row_grads(toffs_c, T, idc, gc, D, bag_len=L), 0.01, 1e-8)
+
+        cpu_step()
+        t0, k = time.perf_counter(), 0
+        while k < args.cpu_steps and time.perf_counter() - t0 < 20.0:
+            cpu_step()
+            k += 1
+        cdt = time.perf_counter() - t0
+        res['cpu_baseline'] = dict(value=round(k * Bc / cdt, 1), unit='samples/s', cores=1, kind='port',
+                                   sample='%d steps of batch %d, same table count / dim / bag length with tables cut to '
+                                          '%d rows each (%.1f GB), through the numpy oracle (single thread)'
+                                          % (k, Bc, rc, T * rc * D * 4 / 1e9))
+    return res
+
+
 def bench_din(args):
     """DIN local activation unit (1 M items x dim 64, history 100, lengths U[1,100], MLP 256-80-40-1), batch 8192."""
     from recommendation_amd import ops
@@ -386,7 +494,8 @@ def main():
         if args.gpus != 1 or int(os.environ.get('WORLD_SIZE', '1')) != 1:
             raise SystemExit("--workload %s is a single-GPU configuration" % args.workload)
         torch.cuda.set_device(0)
-        print(json.dumps(bench_dcn(args) if args.workload == 'dcn' else bench_din(args)))
+        fn = {'dcn': bench_dcn, 'din': bench_din, 'embag': bench_embag}[args.workload]
+        print(json.dumps(fn(args)))
         return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

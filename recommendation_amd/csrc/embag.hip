@@ -139,6 +139,74 @@ __global__ __launch_bounds__(EMBAG_BLOCK) void embag_fwd_kernel(
   if (bad && c == 0 && err) atomicOr(err, bad);
 }
 
+// One id per bag (the one-hot encoders, Criteo-style categorical fields): a lane group serves
+// L1_ROWS bags and issues their id loads, then their row loads, together, so that a thread has
+// L1_ROWS 16-byte row reads in flight instead of one; the kernel is bound by how many bytes the
+// chip keeps in flight against HBM latency, not by arithmetic.  Same results as the general kernel.
+constexpr int L1_ROWS = 4;
+template <typename IDX, bool BF16, bool NT>
+__global__ __launch_bounds__(EMBAG_BLOCK) void embag_fwd_l1_kernel(
+    const float* __restrict__ weights, const int64_t* __restrict__ toffs, int T, int dim, int lanes,
+    int groups, const void* __restrict__ indices, int n_bags, int flags, const float* __restrict__ bias,
+    void* __restrict__ out, int64_t out_ld, int32_t* __restrict__ err) {
+  const int sub = threadIdx.x / lanes;
+  const int c = threadIdx.x - sub * lanes;
+  if (sub >= groups) return;
+  // bags of a block: [blockIdx.x * groups * L1_ROWS, ...); row u of group `sub` is bag0 + u*groups + sub, so
+  // that the stores of one u are contiguous over the block
+  const int bag0 = blockIdx.x * groups * L1_ROWS;
+  int64_t id[L1_ROWS];
+  int bag[L1_ROWS], tt[L1_ROWS];
+#pragma unroll
+  for (int u = 0; u < L1_ROWS; ++u) {
+    bag[u] = bag0 + u * groups + sub;
+    id[u] = bag[u] < n_bags ? mi_ld_id<IDX>(indices, bag[u]) : (int64_t) -1;
+  }
+  int bad = 0;
+  Acc<4> r[L1_ROWS];
+#pragma unroll
+  for (int u = 0; u < L1_ROWS; ++u) {
+    const int b = bag[u] / T;
+    tt[u] = bag[u] - b * T;
+    const bool present = bag[u] < n_bags;
+    const int64_t base = present ? toffs[tt[u]] : 0;
+    const int64_t rows = present ? toffs[tt[u] + 1] - base : 0;
+    if (present) {
+      if (id[u] < 0) {
+        if (flags & MI_CHECK_NONNEG) bad |= MI_IDERR_RANGE;
+      } else if (id[u] >= rows && (flags & MI_CHECK_RANGE)) {
+        bad |= MI_IDERR_RANGE;
+      }
+    }
+    if (present && id[u] >= 0 && id[u] < rows) {
+      ld_row<4>(weights + (base + id[u]) * dim + (int64_t) c * 4, r[u]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[u].v[k] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < L1_ROWS; ++u) {
+    if (bag[u] >= n_bags) continue;
+    if (bias) {
+      Acc<4> bv;
+      ld_row<4>(bias + (int64_t) tt[u] * dim + (int64_t) c * 4, bv);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[u].v[k] += bv.v[k];
+    }
+    const int b = bag[u] / T;
+    if constexpr (NT && !BF16) {  // four adjacent dword streaming stores: merged into one 16-byte store
+      float* o = reinterpret_cast<float*>(out) + (int64_t) b * out_ld + (int64_t) tt[u] * dim + (int64_t) c * 4;
+      __builtin_nontemporal_store(r[u].v[0], o);
+      __builtin_nontemporal_store(r[u].v[1], o + 1);
+      __builtin_nontemporal_store(r[u].v[2], o + 2);
+      __builtin_nontemporal_store(r[u].v[3], o + 3);
+    } else
+    st_out<4, BF16>(out, (int64_t) b * out_ld + (int64_t) tt[u] * dim + (int64_t) c * 4, r[u]);
+  }
+  if (bad && c == 0 && err) atomicOr(err, bad);
+}
+
 template <typename IDX>
 __global__ __launch_bounds__(256) void onehot_dense_kernel(const void* __restrict__ indices, int bag_len,
                                                           int n_bags, int size, int flags,
@@ -216,6 +284,22 @@ int launch_fwd(const float* weights, const int64_t* toffs, int T, int dim, const
   MI_REQUIRE(lanes >= 1 && lanes <= EMBAG_BLOCK, "mi_embag_fwd: dim %d needs %d lanes per bag (max %d)", dim,
              lanes, EMBAG_BLOCK);
   const int bpb = EMBAG_BLOCK / lanes;
+  if (vec4 && !offsets && bag_len == 1 && n_bags >= 65536) {
+    // one id per bag and enough bags to fill the chip several times over: the batched kernel
+    // an fp32 output larger than the 256 MB last-level cache is written with streaming stores: its
+    // reader cannot find it on chip anyway, and the gathered rows keep the cache
+    const bool nt = out_dtype != MI_DT_BF16 && (int64_t) n_bags * dim * 4 > ((int64_t) 256 << 20);
+#define L1(BF, NT_)                                                                                                 \
+  hipLaunchKernelGGL((embag_fwd_l1_kernel<IDX, BF, NT_>), dim3((unsigned) mi_cdiv(n_bags, bpb * L1_ROWS)),          \
+                     dim3(EMBAG_BLOCK), 0, s, weights, toffs, T, dim, lanes, bpb, indices, n_bags, flags, bias, out, \
+                     out_ld, err)
+    if (out_dtype == MI_DT_BF16) L1(true, false);
+    else if (nt) L1(false, true);
+    else L1(false, false);
+#undef L1
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+  }
   const unsigned grid = (unsigned) mi_cdiv(n_bags, bpb);
 #define LAUNCH(V, BF)                                                                                   \
   hipLaunchKernelGGL((embag_fwd_kernel<IDX, V, BF>), dim3(grid), dim3(EMBAG_BLOCK), 0, s, weights, toffs, T, \

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Two rocprofv3 counter_collection.csv files (one --pmc FETCH_SIZE pass, one --pmc WRITE_SIZE pass of the
 same command) -> the per-kernel HBM traffic JSON that bench.py reads for roofline.traffic.
-usage: pmc_json.py fetch.csv write.csv > profiles/<name>_pmc.json"""
+usage: pmc_json.py fetch.csv write.csv [workload-name "bench.py arguments"] > profiles/<name>_pmc.json"""
 import csv
 import json
 import re
@@ -31,14 +31,17 @@ def collect(path, counter):
 
 fetch = collect(sys.argv[1], 'FETCH_SIZE')
 write = collect(sys.argv[2], 'WRITE_SIZE')
-cmd = "rocprofv3 --pmc %s --output-format csv -d out -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 --stage-reps 5"
+workload = sys.argv[3] if len(sys.argv) > 3 else "fm_criteo_26x16_b8192"
+bench_args = sys.argv[4] if len(sys.argv) > 4 else "--no-cpu-baseline --steps 20 --warmup 5 --stage-reps 5"
+cmd = "rocprofv3 --pmc %s --output-format csv -d out -- python3 bench.py " + bench_args
 out = {
-    "what": "HBM traffic per launch from rocprofv3 PMC counters, FM bench (batch 8192, Adam), MI355X",
+    "what": "HBM traffic per launch from rocprofv3 PMC counters, %s, MI355X"
+            % ("FM bench (batch 8192, Adam)" if len(sys.argv) <= 3 else "bench.py workload " + workload),
     "commands": [cmd % "FETCH_SIZE", cmd % "WRITE_SIZE"],
     "corrections": "FETCH_SIZE and WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, "
                    "so it is doubled (MI355X_MICROARCH, HBM section); WRITE_SIZE is taken as is. hbm_bytes_per_launch = "
                    "2*1024*FETCH_SIZE + 1024*WRITE_SIZE, medians over the launches of a kernel.",
-    "workload": "fm_criteo_26x16_b8192",
+    "workload": workload,
     "kernels": {},
 }
 for k in fetch:

@@ -43,6 +43,38 @@ def test_embag_fwd_single_id_rows_bit_exact(dev, dim, idx_dtype):
     assert np.array_equal(out.cpu().numpy(), expect)
 
 
+@pytest.mark.parametrize("dim", [16, 128])
+@pytest.mark.parametrize("idx_dtype", [np.int32, np.int64])
+def test_embag_fwd_many_single_id_bags_bit_exact(dev, dim, idx_dtype):
+    """From 65536 bags of one id on, a lane group serves four bags at once: the output must still be
+    the gathered rows bit for bit (+ bias, fp32 and bf16), ids outside their table give zero rows and
+    are reported, and a bag count that does not fill the last workgroup is handled."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(11)
+    rows = [7, 1, 3000, 1000, 3]
+    w, toffs = make_tables(rng, rows, dim)
+    B, T = 13109, len(rows)                      # 65545 bags
+    ids = np.stack([rng.integers(0, r, size=B) for r in rows], axis=1).astype(idx_dtype)
+    wd, td = torch.from_numpy(w).to(dev), torch.from_numpy(toffs).to(dev)
+    out = ops.embag_fwd(wd, td, T, torch.from_numpy(ids).to(dev), bag_len=1)
+    expect = w[ids + toffs[:-1][None, :]].reshape(B, T * dim)
+    assert np.array_equal(out.cpu().numpy(), expect)
+    bias = rng.standard_normal(T * dim).astype(np.float32)
+    outb = ops.embag_fwd(wd, td, T, torch.from_numpy(ids).to(dev), bag_len=1, bias=torch.from_numpy(bias).to(dev))
+    assert np.array_equal(outb.cpu().numpy(), expect + bias[None, :])
+    out16 = ops.embag_fwd(wd, td, T, torch.from_numpy(ids).to(dev), bag_len=1, out_dtype=torch.bfloat16)
+    assert torch.equal(out16, out.to(torch.bfloat16))
+    bad = ids.copy()
+    bad[5, 2], bad[B - 1, 4], bad[77, 0] = rows[2], 1 << 20, -1
+    err = ops.new_error_word(dev)
+    outx = ops.embag_fwd(wd, td, T, torch.from_numpy(bad).to(dev), bag_len=1, check_flags=ops.MI_CHECK_RANGE, err=err)
+    ex = expect.copy().reshape(B, T, dim)
+    ex[5, 2], ex[B - 1, 4], ex[77, 0] = 0, 0, 0
+    assert np.array_equal(outx.cpu().numpy(), ex.reshape(B, T * dim))
+    with pytest.raises(ops.InvalidArgumentError):
+        ops.check_error_word(err, "ids")
+
+
 @pytest.mark.parametrize("mode", ["sum", "mean"])
 @pytest.mark.parametrize("dim", [4, 8, 16, 5])
 def test_embag_fwd_fixed_bags_with_padding(dev, mode, dim):
