@@ -41,7 +41,8 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=8192, help='batch per GPU')
     ap.add_argument('--dim', type=int, default=16)
-    ap.add_argument('--opt', default='adam_tf', choices=['sgd', 'adagrad_rowwise', 'adam_tf'])
+    ap.add_argument('--opt', default=None, choices=['sgd', 'adagrad_rowwise', 'adam_tf'],
+                    help='table optimizer (default adam_tf, the form of the reference\'s tf.train.AdamOptimizer)')
     ap.add_argument('--dist', default='uniform', choices=['uniform', 'zipf'])
     ap.add_argument('--idx-bits', type=int, default=64, choices=[32, 64])
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -62,7 +63,10 @@ def parse_args():
                     help='embag workload: total rows over the 26 tables (default: one GPU\'s eighth of 1 G rows)')
     ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer', 'embag'],
                     help='fm (default, the headline configuration); dcn / din: the bf16 matrix-core configurations, 1 GPU')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.opt is None:
+        args.opt = 'adam_tf'
+    return args
 
 
 def gen_batches(n_batches, B, rows, n_dense, dist, idx_bits, dev, seed):
@@ -297,9 +301,10 @@ def bench_dcn(args):
 
 
 def bench_embag(args):
-    """Embedding gather + sum pooling forward and the sort-based backward with the fused row-wise
-    Adagrad update, on one GPU's share of the sharded-table configuration: 26 tables, 125 M rows x
-    dim 128 fp32 (64 GB), batch 65536.  The upstream gradient is a fixed synthetic buffer."""
+    """Embedding gather + sum pooling forward and the sort-based backward with the fused
+    optimizer (TensorFlow-form Adam unless --opt says otherwise), on one GPU's share of the sharded-table
+    configuration: 26 tables, 125 M rows x dim 128 fp32 (64 GB, 192 GB with Adam's two moments), batch
+    65536.  The upstream gradient is a fixed synthetic buffer."""
     from recommendation_amd import ops
     dev = torch.device('cuda', 0)
     T, L = 26, args.bag_len
@@ -315,7 +320,9 @@ def bench_embag(args):
     for lo in range(0, total, chunk):
         hi = min(lo + chunk, total)
         W[lo:hi] = torch.randn((hi - lo, D), generator=g, dtype=torch.float32, device=dev).mul_(0.05)
-    state = torch.zeros((total,), dtype=torch.float32, device=dev)
+    opt = args.opt
+    state = torch.zeros((total,), dtype=torch.float32, device=dev) if opt == 'adagrad_rowwise' else None
+    am, av = (torch.zeros_like(W), torch.zeros_like(W)) if opt == 'adam_tf' else (None, None)
     card = torch.tensor(rows, dtype=torch.float64, device=dev).view(1, T, 1)
     idt = torch.int64 if args.idx_bits == 64 else torch.int32
     batches = []
@@ -337,7 +344,12 @@ def bench_embag(args):
         ops.embag_fwd(W, toffs, T, ids, bag_len=L, check_flags=ops.MI_CHECK_RANGE, err=err, out=out)
 
     def upd():
-        ops.bwd_apply_adagrad_rowwise(plan, grad, W, state, 0.01, 1e-8)
+        if opt == 'adagrad_rowwise':
+            ops.bwd_apply_adagrad_rowwise(plan, grad, W, state, 0.01, 1e-8)
+        elif opt == 'sgd':
+            ops.bwd_apply_sgd(plan, grad, W, 0.01)
+        else:
+            ops.bwd_apply_adam_tf(plan, grad, W, am, av, 1e-3, 0.9, 0.999, 1e-8)
 
     def step():
         ids = batches[it[0] % len(batches)]
@@ -352,16 +364,17 @@ def bench_embag(args):
     ib = args.idx_bits // 8
     res = _line(args, 'embag_26x%d_rows%dM_b%d_l%d' % (D, total // 1000000, B, L), B, dt, 'f32',
                 dict(tables=T, total_rows=total, dim=D, bag_len=L, pooling='sum', id_bits=args.idx_bits, ids=args.dist,
-                     table_bytes=total * D * 4, optimizer='adagrad_rowwise (fused into the sparse backward)'))
+                     table_bytes=total * D * 4, optimizer='%s (fused into the sparse backward)' % opt))
     ids = batches[0]
     plan.prepare(ids)
     U = int(torch.unique(plan.sorted_rows[:n]).numel())
     fwd_bytes = n * (D * 4 + ib) + B * T * D * 4
-    upd_bytes = n * 8 + (n if L == 1 else B * T) * D * 4 + U * (D * 4 + 4) * 2
+    state_floats = {'sgd': 0, 'adagrad_rowwise': 1, 'adam_tf': 2 * D}[opt]
+    upd_bytes = n * 8 + (n if L == 1 else B * T) * D * 4 + U * (D + state_floats) * 4 * 2
     stages = []
     for name, fn, nb in (('embag_fwd (gather + sum pooling)', lambda: fwd(ids), fwd_bytes),
                          ('sort_by_row', lambda: plan.prepare(ids), n * (ib + 8)),
-                         ('sparse backward + fused row-wise adagrad', upd, upd_bytes)):
+                         ('sparse backward + fused %s' % opt, upd, upd_bytes)):
         ms = time_stage(fn, args.stage_reps)
         stages.append(dict(name=name, ms=round(ms, 5), alg_bytes=int(nb), gbs=round(nb / ms / 1e6, 1)))
     res['stages'] = stages
@@ -372,7 +385,7 @@ def bench_embag(args):
     kern = 'embag_fwd_kernel' if dom is stages[0] else 'seg_sorted_kernel'
     res['roofline'] = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': round(dom['gbs'] / HBM_PEAK_GBS, 4),
-                       'traffic': _pmc_traffic('r01_embag_b65536_pmc.json', res['config']['workload'], kern),
+                       'traffic': _pmc_traffic('r01_embag_b65536_%s_pmc.json' % opt, res['config']['workload'], kern),
                        'alg_bytes_per_launch': dom['alg_bytes'], 'ms_per_launch': dom['ms']}
     if not args.no_cpu_baseline:
         from oracle import embedding as oe
@@ -381,12 +394,19 @@ def bench_embag(args):
         toffs_c = np.arange(T + 1, dtype=np.int64) * rc
         Wc = (rng.standard_normal((T * rc, D)) * 0.05).astype(np.float32)
         stc = np.zeros(T * rc, np.float32)
+        mc, vc = (np.zeros_like(Wc), np.zeros_like(Wc)) if opt == 'adam_tf' else (None, None)
         idc = rng.integers(0, rc, size=(Bc, T, L)).astype(np.int64)
         gc = (rng.standard_normal((Bc, T * D)) * 1e-3).astype(np.float32)
 
         def cpu_step():
             oe.embag_fwd(Wc, toffs_c, T, idc, bag_len=L)
-            oe.apply_adagrad_rowwise(Wc, stc, oe.row_grads(toffs_c, T, idc, gc, D, bag_len=L), 0.01, 1e-8)
+            grads = oe.row_grads(toffs_c, T, idc, gc, D, bag_len=L)
+            if opt == 'adagrad_rowwise':
+                oe.apply_adagrad_rowwise(Wc, stc, grads, 0.01, 1e-8)
+            elif opt == 'sgd':
+                oe.apply_sgd(Wc, grads, 0.01)
+            else:
+                oe.apply_adam_tf(Wc, mc, vc, grads, 1e-3, 0.9, 0.999, 1e-8)
 
         cpu_step()
         t0, k = time.perf_counter(), 0
