@@ -1,0 +1,68 @@
+"""The benchmark's command line: defaults, the launcher check, and (on a GPU) that each workload
+prints exactly one JSON line with the fields the harness reads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+REQUIRED = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'data', 'config', 'roofline')
+
+
+def _run(*argv, timeout=300):
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, BENCH] + list(argv), cwd=ROOT, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_defaults(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(sys, 'argv', ['bench.py'])
+    a = bench.parse_args()
+    assert (a.gpus, a.workload, a.batch, a.dim, a.opt, a.idx_bits) == (1, 'fm', 8192, 16, 'adam_tf', 64)
+    assert a.steps > 0 and a.warmup >= 0
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--workload', 'embag', '--opt', 'adagrad_rowwise'])
+    assert bench.parse_args().opt == 'adagrad_rowwise'
+
+
+def test_more_gpus_than_ranks_needs_the_launcher():
+    r = _run('--gpus', '2', timeout=120)
+    assert r.returncode != 0 and 'torch.distributed.run' in r.stderr and r.stdout.strip() == ''
+
+
+def _one_json_line(r):
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d['value'] > 0 and d['ms_per_step'] > 0 and 'workload' in d['config']
+    rf = d['roofline']
+    assert rf['bound'] in ('hbm', 'mfma') and rf['peak'] > 0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
+    return d
+
+
+@pytest.mark.gpu
+def test_fm_line(dev):
+    d = _one_json_line(_run('--steps', '5', '--warmup', '2', '--stage-reps', '2', '--cpu-steps', '1'))
+    assert d['config']['workload'] == 'fm_criteo_26x16_b8192' and d['n_gpus'] == 1 and d['steps'] == 5
+    assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['value'] > 0
+    assert d['config']['id_layout'].startswith('field-major')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt", ['adam_tf', 'adagrad_rowwise', 'sgd'])
+def test_embag_line_small_tables(dev, opt):
+    d = _one_json_line(_run('--workload', 'embag', '--embag-rows', '2600000', '--opt', opt, '--steps', '3', '--warmup',
+                            '1', '--stage-reps', '2', '--no-cpu-baseline'))
+    assert d['config']['dim'] == 128 and d['config']['optimizer'].startswith(opt)
+    assert d['embedding_hbm_gbs'] > 0 and len(d['stages']) == 3
