@@ -92,6 +92,7 @@ __device__ __forceinline__ void stv(float* p, const float* o) {
 // ---- per-entry sources ------------------------------------------------------------------
 // gradient of the pooled bag output
 struct BagGradSrc {
+  static constexpr bool kBatchSingles = true;  // light per-entry state: four single-entry runs per lane group at once
   const float* grad_out;
   int64_t grad_ld;
   int dim;
@@ -114,6 +115,7 @@ struct BagGradSrc {
 // The sample of entry p is p / T, or entry_sample[p] when given (sharded tables: the entries an
 // owner received from all ranks, each tagged with its requester's sample).
 struct FmSrc {
+  static constexpr bool kBatchSingles = false;  // (measured: the extra registers cost the FM step more than they gain)
   const float* g;
   const float* S;
   int g_ld, S_ld;  // floats between consecutive samples (1 and dim when g and S are separate arrays)
@@ -196,6 +198,9 @@ __device__ __forceinline__ void opt_finish(float* w, float* s0, float* s1, int d
 // ---- row updaters: load(row) early, finish(row, summed gradient) late -----------------------
 template <int OPT>
 struct BagUpd {
+  // four rows' state at once (see seg_sorted_kernel): pays for SGD and Adagrad; Adam's two moment rows
+  // per row make the registers of four rows cost more occupancy than the batching gains (measured)
+  static constexpr bool kBatchSingles = OPT != MI_OPT_ADAM_TF;
   float* w; float* s0; float* s1; int dim; OptArgs a;
   template <int VEC> using Regs = OptRegs<OPT, VEC>;
   __device__ __forceinline__ float* p0(int64_t row) const {
@@ -214,6 +219,7 @@ struct BagUpd {
 
 struct NoRegs {};
 struct DenseGradUpd {
+  static constexpr bool kBatchSingles = true;
   float* dW; int dim;
   template <int VEC> using Regs = NoRegs;
   template <int VEC>
@@ -232,6 +238,7 @@ struct FmRegs {
 };
 template <int OPT>
 struct FmUpd {
+  static constexpr bool kBatchSingles = false;
   mi_fm_table t; OptArgs a;
   template <int VEC> using Regs = FmRegs<OPT, VEC>;
   template <int VEC>
@@ -736,6 +743,42 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
   const unsigned long long hm = __ballot(head);
   const int nheads = __popcll(hm);
   const int G = 64 / lanes, g = lane / lanes, c = lane - g * lanes;
+  if constexpr (Src::kBatchSingles && Upd::kBatchSingles) {
+    // A full wave whose 64 entries are 64 different rows, none of them padding and the last one not
+    // continued in the next wave (the usual case once the tables are much larger than the batch):
+    // every run is one entry, so a lane group takes four of them per round - four permutation entries
+    // and row states requested together, then the four gradient rows - instead of one run per round.
+    // Nothing in the round is conditional (a branch around a load makes the compiler wait for all
+    // outstanding loads where the paths join, which would serialise the four again).
+    const uint32_t last_key = (uint32_t) __shfl((int) key, 63, 64);
+    if (hm == ~0ull && lanes >= 4 && base + 64 <= pl.n && last_key != sentinel &&
+        !(base + 64 < pl.n && after_wave == last_key)) {  // uniform
+      constexpr int BT = 4;
+      for (int r0 = 0; r0 < lanes; r0 += BT) {  // 64 / G = lanes rounds, a power of two >= 4
+        uint32_t row[BT];
+        int p[BT];
+        typename Upd::template Regs<VEC> regs[BT];
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+          const int pos = (r0 + u) * G + g;
+          row[u] = (uint32_t) __shfl((int) key, pos, 64);
+          p[u] = pl.perm[base + pos];
+          upd.template load<VEC>((int64_t) row[u], c, regs[u]);
+        }
+        float v[BT][VEC], sc[BT];
+#pragma unroll
+        for (int u = 0; u < BT; ++u) src.template load<VEC>(pl, p[u], c, v[u], sc[u]);
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+          float acc[VEC];
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) acc[k] = 0.f + v[u][k];  // the sum of a one-entry run, as group_run forms it
+          upd.template finish<VEC>((int64_t) row[u], c, lanes, regs[u], acc, 0.f + sc[u]);
+        }
+      }
+      return;
+    }
+  }
   for (int r = 0; r * G < nheads; ++r) {  // uniform over the wave
     const int k = r * G + g;
     const int pos = k < nheads ? kth_set_bit(hm, k) : 0;

@@ -293,6 +293,51 @@ def test_fused_sparse_updates(dev, opt):
     assert rel_err(wd.cpu().numpy(), wr) <= TOL
 
 
+@pytest.mark.parametrize("dim", [16, 128])
+def test_sparse_update_waves_of_distinct_rows(dev, dim):
+    """Tables much larger than the batch: most waves of the run-finding kernel hold 64 different rows and
+    take four of them per lane group at once.  Table 0's ids are all distinct (every wave of it is such a
+    wave), table 1's repeat (the general path), and the boundary waves mix both.  A one-entry run's
+    gradient is the entry's own gradient row, so the dense gradient is exact; SGD and row-wise Adagrad
+    are held to the oracle's formulas."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(31)
+    rows = [300000, 200000]
+    T, B = 2, 4096 + 37
+    toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    total = int(toffs[-1])
+    ids = np.stack([rng.permutation(rows[0])[:B], rng.integers(0, 900, size=B)], axis=1).astype(np.int64)[:, :, None]
+    grad = rng.standard_normal((B, T * dim)).astype(np.float32)
+    w = (rng.standard_normal((total, dim)) * 0.1).astype(np.float32)
+    plan = ops.SortedPlan(torch.from_numpy(toffs).to(dev), T, total, torch.from_numpy(ids).to(dev), bag_len=1,
+                          runs=False)
+    g = torch.from_numpy(grad).to(dev)
+    dW = ops.bwd_dense_grad(plan, g, dim, total).cpu().numpy()
+    assert np.array_equal(dW[ids[:, 0, 0]], grad[:, :dim] + 0.0)          # table 0: exact
+    want = oe.row_grads(toffs, T, ids, grad, dim, bag_len=1)
+    dense = np.zeros((total, dim), np.float64)
+    for r, v in want.items():
+        dense[r] = v
+    assert rel_err(dW, dense) <= RTOL
+    grads = {int(r): dW[int(r)].astype(np.float64) for r in want}
+    lr, eps, TOL = 0.05, 1e-8, 2e-6
+    wd = torch.from_numpy(w.copy()).to(dev)
+    ops.bwd_apply_sgd(plan, g, wd, lr)
+    wr = w.astype(np.float64)
+    oe.apply_sgd(wr, grads, lr)
+    assert rel_err(wd.cpu().numpy(), wr) <= TOL
+    st = rng.random(total).astype(np.float32)
+    wd, std = torch.from_numpy(w.copy()).to(dev), torch.from_numpy(st.copy()).to(dev)
+    ops.bwd_apply_adagrad_rowwise(plan, g, wd, std, lr, eps)
+    wr, sr = w.astype(np.float64), st.astype(np.float64)
+    oe.apply_adagrad_rowwise(wr, sr, grads, lr, eps)
+    assert rel_err(std.cpu().numpy(), sr) <= TOL and rel_err(wd.cpu().numpy(), wr) <= TOL
+    # untouched rows keep their bits
+    mask = np.ones(total, bool)
+    mask[list(want)] = False
+    assert np.array_equal(wd.cpu().numpy()[mask], w[mask])
+
+
 def test_sparse_update_is_bitwise_reproducible(dev):
     from recommendation_amd import ops
     rng = np.random.default_rng(8)
