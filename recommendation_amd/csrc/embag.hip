@@ -284,8 +284,9 @@ int launch_fwd(const float* weights, const int64_t* toffs, int T, int dim, const
   MI_REQUIRE(lanes >= 1 && lanes <= EMBAG_BLOCK, "mi_embag_fwd: dim %d needs %d lanes per bag (max %d)", dim,
              lanes, EMBAG_BLOCK);
   const int bpb = EMBAG_BLOCK / lanes;
-  if (vec4 && !offsets && bag_len == 1 && n_bags >= 65536) {
-    // one id per bag and enough bags to fill the chip several times over: the batched kernel
+  if (vec4 && !offsets && bag_len == 1 && n_bags >= 65536 && n_bags < (1 << 30)) {
+    // one id per bag and enough bags to fill the chip several times over: the batched kernel (its bag
+    // numbers run up to a workgroup's worth past n_bags, kept well inside an int)
     // an fp32 output larger than the 256 MB last-level cache is written with streaming stores: its
     // reader cannot find it on chip anyway, and the gathered rows keep the cache
     const bool nt = out_dtype != MI_DT_BF16 && (int64_t) n_bags * dim * 4 > ((int64_t) 256 << 20);
