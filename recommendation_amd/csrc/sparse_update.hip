@@ -754,7 +754,10 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
     // outstanding loads where the paths join, which would serialise the four again).
     const uint32_t last_key = (uint32_t) __shfl((int) key, 63, 64);
     constexpr int BT = Upd::kBatchSingles;  // rows per lane group per round
-    if (hm == ~0ull && lanes >= BT && base + 64 <= pl.n && last_key != sentinel &&
+    // (a per-table sort leaves padding entries at the end of each TABLE's block, so a lone one can sit
+    // anywhere in the wave and still differ from both neighbours: every lane is checked, not the last)
+    const bool no_padding = __ballot(key == sentinel) == 0ull;
+    if (hm == ~0ull && lanes >= BT && base + 64 <= pl.n && no_padding &&
         !(base + 64 < pl.n && after_wave == last_key)) {  // uniform
       for (int r0 = 0; r0 < lanes; r0 += BT) {  // 64 / G = lanes rounds, a power of two >= BT
         uint32_t row[BT];

@@ -56,6 +56,7 @@ class FactorizationMachine(object):
         self.steps = 0
         self.err = ops.new_error_word(self.device)
         self._buf_B = None
+        self._bufsets = {}                     # (B, id dtype) -> (buffers, loss, plan); kept, so captured graphs stay valid
         self._graphs = {}
         self._side = None
         self.fused = True                      # set False to run the step as five separate launches
@@ -93,11 +94,17 @@ class FactorizationMachine(object):
         B = ids.shape[0]
         key = (B, ids.dtype)
         if self._buf_B != key:
-            f32 = dict(dtype=torch.float32, device=self.device)
-            self.buf = dict(logit=torch.empty((B,), **f32), S=torch.empty((B, self.dim), **f32),
-                            loss_rows=torch.empty((B,), **f32), g=torch.empty((B,), **f32))
-            self.loss = torch.empty((1,), **f32)
-            self.plan = ops.SortedPlan(self.toffs, self.T, self.total_rows, ids, bag_len=1, runs=False)
+            # One buffer set per batch shape, never freed while the model lives: a HIP graph captured
+            # for one shape keeps pointing at that shape's buffers after steps of another shape (a
+            # ragged last batch) ran in between.
+            if key not in self._bufsets:
+                f32 = dict(dtype=torch.float32, device=self.device)
+                buf = dict(logit=torch.empty((B,), **f32), S=torch.empty((B, self.dim), **f32),
+                           loss_rows=torch.empty((B,), **f32), g=torch.empty((B,), **f32))
+                loss = torch.empty((1,), **f32)
+                plan = ops.SortedPlan(self.toffs, self.T, self.total_rows, ids, bag_len=1, runs=False)
+                self._bufsets[key] = (buf, loss, plan)
+            self.buf, self.loss, self.plan = self._bufsets[key]
             self._buf_B = key
         return self.buf
 
@@ -161,7 +168,7 @@ class FactorizationMachine(object):
         lets a table's sort load its ids as whole lines."""
         self._buffers(ids)
         if graph:
-            key = (ids.data_ptr(), dense.data_ptr(), labels.data_ptr(), ids.shape[0],
+            key = (ids.data_ptr(), dense.data_ptr(), labels.data_ptr(), ids.shape[0], ids.dtype,
                    ids_tm.data_ptr() if ids_tm is not None else 0)
             g = self._graphs.get(key)
             if g is None:

@@ -658,3 +658,72 @@ def test_piecewise_long_runs_exact_and_reproducible(dev):
         outs.append(w.cpu().numpy())
     assert np.array_equal(outs[0], want.astype(np.float32))
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("dim", [16, 128])
+def test_lone_padding_id_inside_a_wave_of_distinct_rows(dev, dim):
+    """The per-table sort (plan without run arrays, <= 8192 entries per table) leaves a table's padding
+    entries at the end of THAT table's block, i.e. in the middle of the array.  With all other ids
+    distinct, a single -1 id in table 0 is a lone entry that differs from both neighbours; the wave that
+    holds it must not treat it as a row (it would read and write one row past the tables).  Buffers
+    carry a guard row behind total_rows, which must keep its bits; results equal the oracle's."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(41)
+    rows = [5000, 7000, 3000]
+    T, B = 3, 1024
+    toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    total = int(toffs[-1])
+    ids = np.stack([rng.permutation(r)[:B] for r in rows], axis=1).astype(np.int64)[:, :, None]
+    ids[100, 0, 0] = -1                                          # exactly one padding id, in table 0
+    grad = rng.standard_normal((B, T * dim)).astype(np.float32)
+    w = (rng.standard_normal((total + 1, dim)) * 0.1).astype(np.float32)     # row `total` is the guard
+    td = torch.from_numpy(toffs).to(dev)
+    plan = ops.SortedPlan(td, T, total, torch.from_numpy(ids).to(dev), bag_len=1, runs=False)
+    sr = plan.sorted_rows.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert sr[B - 1] == total and (sr[:B - 1] < total).all() and (sr[B:] < total).all()   # sentinel mid-array
+    g = torch.from_numpy(grad).to(dev)
+    want = oe.row_grads(toffs, T, ids, grad, dim, bag_len=1)
+    dense = oe.dense_grad(total, dim, want)
+    # dense gradient into a buffer with a guard row
+    dW = torch.full((total + 1, dim), 7.0, device=dev)
+    from recommendation_amd import _lib
+    _lib.call('mi_embag_bwd_dense_grad', plan.ref(), ops._p(g), T * dim, dim, total, ops._p(dW), ops._stream())
+    dWh = dW.cpu().numpy()
+    assert np.array_equal(dWh[total], np.full(dim, 7.0, np.float32))
+    assert rel_err(dWh[:total], dense) <= RTOL
+    grads = {int(r): dWh[int(r)].astype(np.float64) for r in want}
+    lr, eps, TOL = 0.05, 1e-8, 2e-6
+    wd = torch.from_numpy(w.copy()).to(dev)
+    ops.bwd_apply_sgd(plan, g, wd, lr)
+    wr = w.astype(np.float64)
+    oe.apply_sgd(wr[:total], grads, lr)
+    assert np.array_equal(wd.cpu().numpy()[total], w[total])
+    assert rel_err(wd.cpu().numpy()[:total], wr[:total]) <= TOL
+    st = rng.random(total + 1).astype(np.float32)
+    wd, std = torch.from_numpy(w.copy()).to(dev), torch.from_numpy(st.copy()).to(dev)
+    ops.bwd_apply_adagrad_rowwise(plan, g, wd, std, lr, eps)
+    wr, srf = w.astype(np.float64), st.astype(np.float64)
+    oe.apply_adagrad_rowwise(wr[:total], srf[:total], grads, lr, eps)
+    assert np.array_equal(wd.cpu().numpy()[total], w[total]) and std.cpu().numpy()[total] == st[total]
+    assert rel_err(std.cpu().numpy()[:total], srf[:total]) <= TOL and rel_err(wd.cpu().numpy()[:total], wr[:total]) <= TOL
+
+
+def test_fm_graph_survives_a_batch_of_another_shape(dev):
+    """graph step at B=4096, an eager ragged batch of 1000, then the graph step again: the replayed
+    graph must still read and write live buffers (each batch shape keeps its own buffer set) and the
+    model must match an eager twin bit for bit."""
+    from recommendation_amd.fm import FactorizationMachine
+    rows = [1460, 583, 30000, 305, 24, 3, 10, 4, 18, 15, 105, 27, 2173]
+    ref = ofm.State(rows, 16, 13, seed=5, opt='adam_tf')
+    a = FactorizationMachine(rows, 16, 13, device=dev, opt='adam_tf', lr=1e-2)
+    b = FactorizationMachine(rows, 16, 13, device=dev, opt='adam_tf', lr=1e-2)
+    a.load_state(ref)
+    b.load_state(ref)
+    big = tuple(torch.from_numpy(x).to(dev) for x in ofm.synthetic_batch(4096, rows, 13, seed=61, dist='zipf'))
+    small = tuple(torch.from_numpy(x).to(dev) for x in ofm.synthetic_batch(1000, rows, 13, seed=62, dist='zipf'))
+    for bufs, graph in ((big, True), (small, False), (big, True), (small, False), (big, True)):
+        la = a.train_step(*bufs).clone()
+        lb = b.train_step(*bufs, graph=graph).clone()
+        assert torch.equal(la, lb)
+    assert len(b._graphs) == 1
+    assert torch.equal(a.table.rec, b.table.rec) and torch.equal(a.dp, b.dp)
