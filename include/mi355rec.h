@@ -115,6 +115,22 @@ int mi_embag_bwd_prepare(const int64_t* table_offsets, int T, int64_t total_rows
                          int32_t* seg_offsets, int32_t* counts,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* mi_embag_bwd_prepare for callers that cannot allocate device memory or bring a workspace (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  Same arguments and results as mi_embag_bwd_prepare, minus the
+ * workspace: the sort scratch is a fixed array inside the library's device image (about 18.9 MB
+ * per GPU, held until the process ends), so n_entries is limited to MI_NOALLOC_MAX_ENTRIES;
+ * more returns MI_ERR_WORKSPACE.  The call itself allocates nothing and frees nothing.  All calls on
+ * one GPU share that array: two calls that overlap in time on the same GPU (different streams or
+ * threads) race; calls on one stream, or on different GPUs, do not.  The array keeps the previous
+ * call's contents; every part of it is rewritten before it is read, so nothing needs clearing. */
+#define MI_NOALLOC_MAX_ENTRIES (1 << 21)
+int mi_embag_bwd_prepare_noalloc(const int64_t* table_offsets, int T, int64_t total_rows,
+                                 const void* indices, int idx_bits, const int64_t* offsets, int bag_len,
+                                 int64_t n_bags, int64_t n_entries,
+                                 uint32_t* sorted_rows, int32_t* perm, uint32_t* unique_rows,
+                                 int32_t* seg_offsets, int32_t* counts, void* stream);
+
 /* Generic stable key/value radix sort used by the above (exported for tests).
  * keys/vals are overwritten with the sorted result; key_bits = number of low bits that
  * differ (passes = ceil(key_bits/9), 8- or 9-bit digits). */

@@ -15,6 +15,7 @@ MI_IDERR_RANGE, MI_IDERR_ORDER, MI_IDERR_INTERNAL = 1, 2, 4
 MI_POOL_SUM, MI_POOL_MEAN = 0, 1
 MI_DT_F32, MI_DT_BF16 = 0, 1
 MI_OPT_SGD, MI_OPT_ADAGRAD_ROWWISE, MI_OPT_ADAM_TF = 0, 1, 2
+MI_NOALLOC_MAX_ENTRIES = 1 << 21
 
 
 class MiError(RuntimeError):
@@ -56,6 +57,8 @@ _SIGNATURES = {
     'mi_embag_bwd_workspace_bytes': (c_size_t, [c_int64]),
     'mi_embag_bwd_prepare': (c_int, [P, c_int, c_int64, P, c_int, P, c_int, c_int64, c_int64, P, P, P, P, P,
                                      P, c_size_t, P]),
+    'mi_embag_bwd_prepare_noalloc': (c_int, [P, c_int, c_int64, P, c_int, P, c_int, c_int64, c_int64, P, P, P, P, P,
+                                             P]),
     'mi_sort_pairs_u32': (c_int, [P, P, c_int64, c_int, P, c_size_t, P]),
     'mi_embag_bwd_dense_grad': (c_int, [POINTER(BwdPlan), P, c_int64, c_int, c_int64, P, P]),
     'mi_embag_bwd_apply_sgd': (c_int, [POINTER(BwdPlan), P, c_int64, c_int, P, c_float, P]),

@@ -15,6 +15,7 @@
 // Keys are uint32; a pass costs 4+4 B read and 4+4 B written per pair for scatter and
 // 4 B read for hist: 20 B per pair per pass.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -503,4 +504,57 @@ extern "C" int mi_embag_bwd_prepare(const int64_t* table_offsets, int T, int64_t
                      unique_rows, seg_offsets);
   MI_LAUNCH_CHECK();
   return MI_OK;
+}
+
+// ---- the entry point that allocates nothing ------------------------------------------------
+// Sort scratch for callers that cannot bring a workspace: a fixed array in the library's own
+// device image (every GPU the library runs on holds its own copy until the process ends).
+// `noalloc_scratch` is only a host-side stand-in for the symbol: the device address is looked up
+// once per device with hipGetSymbolAddress and only that pointer is ever handed to kernels.
+constexpr int64_t NOALLOC_MAX_ENTRIES = MI_NOALLOC_MAX_ENTRIES;
+constexpr size_t NOALLOC_SCRATCH_BYTES = 18884864;  // sort_ws_bytes(NOALLOC_MAX_ENTRIES), checked at first use
+static __device__ __align__(256) unsigned char noalloc_scratch[NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int NOALLOC_MAX_DEVICES = 64;
+void* g_noalloc_ptr[NOALLOC_MAX_DEVICES];
+std::mutex g_noalloc_mutex;
+
+// Device address of this device's copy of noalloc_scratch (looked up on the first call per device).
+int noalloc_scratch_ptr(void** out) {
+  int dev = -1;
+  MI_HIP(hipGetDevice(&dev));
+  MI_REQUIRE(dev >= 0 && dev < NOALLOC_MAX_DEVICES, "mi_embag_bwd_prepare_noalloc: device %d outside 0..%d", dev,
+             NOALLOC_MAX_DEVICES - 1);
+  std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+  if (!g_noalloc_ptr[dev]) {
+    void* p = nullptr;
+    MI_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(noalloc_scratch)));
+    MI_REQUIRE(p && ((uintptr_t) p & 255) == 0, "mi_embag_bwd_prepare_noalloc: scratch symbol not resolved");
+    g_noalloc_ptr[dev] = p;
+  }
+  *out = g_noalloc_ptr[dev];
+  return MI_OK;
+}
+}  // namespace
+
+extern "C" int mi_embag_bwd_prepare_noalloc(const int64_t* table_offsets, int T, int64_t total_rows,
+                                            const void* indices, int idx_bits, const int64_t* offsets, int bag_len,
+                                            int64_t n_bags, int64_t n_entries, uint32_t* sorted_rows, int32_t* perm,
+                                            uint32_t* unique_rows, int32_t* seg_offsets, int32_t* counts,
+                                            void* stream) {
+  static_assert(NOALLOC_SCRATCH_BYTES % 256 == 0, "scratch is carved in 256-byte units");
+  if (n_entries < 0 || n_entries > NOALLOC_MAX_ENTRIES || sort_ws_bytes(n_entries) > NOALLOC_SCRATCH_BYTES) {
+    mi_set_error("mi_embag_bwd_prepare_noalloc: n_entries %lld beyond the built-in scratch (at most %lld entries)",
+                 (long long) n_entries, (long long) NOALLOC_MAX_ENTRIES);
+    return MI_ERR_WORKSPACE;
+  }
+  void* ws = nullptr;
+  const int rc = noalloc_scratch_ptr(&ws);
+  if (rc != MI_OK) return rc;
+  // every buffer carved from the scratch is fully written before it is read (alternate key / value
+  // buffers by key generation or a pass, histograms and block counts by their own kernels), so
+  // nothing of the previous call's contents needs clearing
+  return mi_embag_bwd_prepare(table_offsets, T, total_rows, indices, idx_bits, offsets, bag_len, n_bags, n_entries,
+                              sorted_rows, perm, unique_rows, seg_offsets, counts, ws, NOALLOC_SCRATCH_BYTES, stream);
 }

@@ -695,3 +695,18 @@ def din_lau_scatter(A, dA, a, dpooled, dq_extra, ids_all, dim, dE):
 
 def bce_logits(logits, labels, gscale, loss_rows, g):
     _lib.call('mi_bce_logits', _p(logits), _p(labels), logits.numel(), gscale, _p(loss_rows), _p(g), _stream())
+
+
+def bwd_prepare_noalloc(toffs, T, total_rows, indices, sorted_rows, perm, unique_rows=None, seg_offsets=None,
+                        counts=None, offsets=None, bag_len=1):
+    """mi_embag_bwd_prepare on the library's built-in sort scratch: the call allocates nothing (the
+    caller passes every output buffer).  At most MI_NOALLOC_MAX_ENTRIES entries; calls that overlap
+    in time on one GPU share the scratch and race."""
+    _need_cuda(toffs, indices, sorted_rows, perm, unique_rows, seg_offsets, counts, offsets)
+    if not indices.is_contiguous():
+        raise MiError("bwd_prepare_noalloc: indices must be contiguous (a copy would allocate)")
+    n = indices.numel()
+    n_bags = n // max(bag_len, 1) if offsets is None else offsets.numel() - 1
+    _lib.call('mi_embag_bwd_prepare_noalloc', _p(toffs), T, total_rows, _p(indices), _idx_bits(indices), _p(offsets),
+              bag_len if offsets is None else 0, n_bags, n, _p(sorted_rows), _p(perm), _p(unique_rows),
+              _p(seg_offsets), _p(counts), _stream())
