@@ -66,7 +66,7 @@ def test_gradients_and_update(dev):
     m = DCNv2(ROWS, DIM, ND, dev, mlp=mlp, lr=1e-3, emb_lr=1e-2, keep_grads=True)
     m.load_state(st)
     ids, dense, labels = ofm.synthetic_batch(B, ROWS, ND, seed=4, dist='zipf')
-    loss_exact = odcn.grads(st, ids, dense, labels)[0]
+    loss_exact, gx = odcn.grads(st, ids, dense, labels)[:2]          # exact arithmetic: printed, bounded by 5e-2
     loss_want, gr, uniq, dV, k = odcn.grads(st, ids, dense, labels, storage='bf16')
     assert abs(loss_want - loss_exact) <= 1e-2 * abs(loss_exact)
     V_before = m.V.clone()
@@ -78,12 +78,20 @@ def test_gradients_and_update(dev):
     for l in range(3):
         assert rel(got['cross%d/W' % l].grad.cpu().numpy()[:d, :d], gr['cross%d/W' % l]) <= 1e-2, l
         assert rel(got['cross%d/b' % l].grad.cpu().numpy()[:d], gr['cross%d/b' % l]) <= 1e-2, l
+        ex = rel(got['cross%d/W' % l].grad.cpu().numpy()[:d, :d], gx['cross%d/W' % l])
+        exb = rel(got['cross%d/b' % l].grad.cpu().numpy()[:d], gx['cross%d/b' % l])
+        print("cross%d W / b gradient vs the EXACT oracle: %.2e / %.2e" % (l, ex, exb))
+        assert ex <= 5e-2 and exb <= 5e-2
         assert not got['cross%d/W' % l].grad.cpu().numpy()[d:, :].any()      # padding gets no gradient
         assert not got['cross%d/W' % l].grad.cpu().numpy()[:, d:].any()
     for i in range(len(mlp)):
         W = got['mlp%d/W' % i].grad.cpu().numpy()
         assert rel(W[:, :gr['mlp%d/W' % i].shape[1]], gr['mlp%d/W' % i]) <= 1e-2, i
         assert rel(got['mlp%d/b' % i].grad.cpu().numpy(), gr['mlp%d/b' % i]) <= 1e-2, i
+        ex = rel(W[:, :gx['mlp%d/W' % i].shape[1]], gx['mlp%d/W' % i])
+        exb = rel(got['mlp%d/b' % i].grad.cpu().numpy(), gx['mlp%d/b' % i])
+        print("mlp%d W / b gradient vs the EXACT oracle: %.2e / %.2e" % (i, ex, exb))
+        assert ex <= 5e-2 and exb <= 5e-2
     K = mlp[-1]
     wb = got['out/wb'].grad.cpu().numpy()
     assert rel(wb[:K], gr['out/w']) <= 1e-2

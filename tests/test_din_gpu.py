@@ -65,7 +65,7 @@ def test_gradients_and_update(dev, factored):
     m.load_state(st)
     hist, qid, lens, labels = odin.synthetic_batch(B, L, ROWS, seed=4)
     hist[:, :3] = hist[0, :3]                                # rows shared by every sample: long runs
-    loss_exact = odin.grads(st, hist, qid, lens, labels)[0]
+    loss_exact, gx = odin.grads(st, hist, qid, lens, labels)[:2]     # exact arithmetic: printed, bounded by 5e-2
     loss_want, gr, uniq, dE, k = odin.grads(st, hist, qid, lens, labels, storage='bf16', factored=factored)
     assert abs(loss_want - loss_exact) <= 1e-2 * abs(loss_exact)
     E_before = m.E.clone()
@@ -78,6 +78,12 @@ def test_gradients_and_update(dev, factored):
     assert rel(got['lau/W2'].grad.cpu().numpy()[:40, :80], gr['lau/W2']) <= 1e-2
     assert rel(got['lau/b2'].grad.cpu().numpy()[:40], gr['lau/b2']) <= 1e-2
     w3 = got['lau/w3b3'].grad.cpu().numpy()
+    for name, G in (('lau/W1', got['lau/W1'].grad.cpu().numpy()[:80]), ('lau/b1', got['lau/b1'].grad.cpu().numpy()[:80]),
+                    ('lau/W2', got['lau/W2'].grad.cpu().numpy()[:40, :80]), ('lau/b2', got['lau/b2'].grad.cpu().numpy()[:40]),
+                    ('lau/w3', w3[:40])):
+        ex = rel(G, gx[name])
+        print("%s gradient vs the EXACT oracle: %.2e" % (name, ex))
+        assert ex <= 5e-2, name
     assert rel(w3[:40], gr['lau/w3']) <= 1e-2
     assert abs(w3[64] - gr['lau/b3'][0]) <= 1e-2 * max(abs(gr['lau/b3'][0]), np.abs(gr['lau/w3']).max())
     head = got['out/Wb'].grad.cpu().numpy()
