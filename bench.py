@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument('--dist', default='uniform', choices=['uniform', 'zipf'])
     ap.add_argument('--idx-bits', type=int, default=64, choices=[32, 64])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=20)
+    ap.add_argument('--cpu-steps', type=int, default=50)
     ap.add_argument('--stage-reps', type=int, default=50)
     ap.add_argument('--no-graph', action='store_true', help='launch the step eagerly instead of replaying a HIP graph')
     ap.add_argument('--prefetch', action='store_true',
@@ -104,6 +104,29 @@ def time_stage(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def time_rotating(fn, n, reps):
+    """time_stage of fn(j) with j cycling over n prepared inputs (whole cycles only, the first cycle
+    untimed): with enough distinct inputs that more than the 256 MiB last-level cache is touched
+    between two uses of a line, the rate that comes out is an HBM rate, not a cache rate."""
+    for j in range(n):
+        fn(j)
+    it = [0]
+
+    def call():
+        fn(it[0] % n)
+        it[0] += 1
+
+    reps = -(-max(reps, n) // n) * n
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 def sharded_stage_report(m, batch, reps, idx_bits):
     """Per-launch device time and ALGORITHMIC bytes of one rank's share of a sharded FM step, timed on
     the buffers the last step left behind (no collectives inside: they are reported by the step time)."""
@@ -132,17 +155,31 @@ def sharded_stage_report(m, batch, reps, idx_bits):
     return stages, n, U
 
 
-def stage_report(fm, batch, reps, idx_bits, ids_tm=None):
-    """Per-stage device time and ALGORITHMIC bytes of one FM step at this batch."""
+def stage_report(fm, batches, reps, idx_bits, tms=None):
+    """Per-stage device time and ALGORITHMIC bytes of one FM step.  Every stage is timed cycling over
+    ALL the bench's batches, each with its own forward outputs and sorted plan prepared beforehand: a
+    batch touches ~94 k records (24 MB) + 14 MB of S / permutation, eight of them ~0.5 GB, so no line
+    is still in the 256 MiB last-level cache when its batch comes round again.  The update stages run
+    with step size 0 and the model's parameters and optimizer state are restored afterwards."""
     from recommendation_amd import ops
     from recommendation_amd.fm import _OPT
-    ids, dense, labels = batch
-    B, T = ids.shape
+    B, T = batches[0][0].shape
     D, nd = fm.dim, fm.n_dense
     ib = idx_bits // 8
-    r = fm.forward(ids, dense, labels)
-    fm.plan.prepare(ids)
-    U = int(ops.SortedPlan(fm.toffs, T, fm.total_rows, ids, bag_len=1).counts[0].item())
+    n_b = len(batches)
+    saved = (fm.table.rec.clone(), fm.dp.clone(), fm.dm.clone(), fm.dv.clone(), fm.sched.clone())
+    f32 = dict(dtype=torch.float32, device=fm.device)
+    fused = fm.fused and B <= ops.fm_fwd_sort_max_batch()
+    sets, Us = [], []
+    for j, (ids, dense, labels) in enumerate(batches):
+        buf = dict(logit=torch.empty((B,), **f32), S=torch.empty((B, D), **f32), loss_rows=torch.empty((B,), **f32),
+                   g=torch.empty((B,), **f32))
+        plan = ops.SortedPlan(fm.toffs, T, fm.total_rows, ids, bag_len=1, runs=False)
+        ops.fm_fwd(fm.table, fm.toffs, ids, dense if nd else None, fm.wd if nd else None, fm.bias, labels, 1.0 / B,
+                   fm.err, out=buf)
+        sets.append((buf, plan))
+        Us.append(int(torch.unique(plan.sorted_rows).numel()))
+    U = sum(Us) / float(n_b)
     n_state = {'sgd': 0, 'adagrad_rowwise': 1.0 / D, 'adam_tf': 2}[fm.opt]
     n_state_w1 = {'sgd': 0, 'adagrad_rowwise': 1, 'adam_tf': 2}[fm.opt]
     # forward = rows + ids + first-order weights + dense features + logit
@@ -155,38 +192,71 @@ def stage_report(fm, batch, reps, idx_bits, ids_tm=None):
     stages = []
 
     def add(name, fn, nbytes, kernels):
-        ms = time_stage(fn, reps)
+        ms = time_rotating(fn, n_b, reps)
         stages.append(dict(name=name, ms=round(ms, 5), kernels=kernels, alg_bytes=int(nbytes),
                            gbs=round(nbytes / ms / 1e6, 1)))
 
-    fused = fm.fused and B <= ops.fm_fwd_sort_max_batch()
-    nd_arg = dense if nd else None
+    def nd_arg(j):
+        return batches[j][1] if nd else None
+
+    def fwd_sort(j):
+        ids, dense, labels = batches[j]
+        ops.fm_fwd_sort(fm.table, fm.toffs, ids, sets[j][1], nd_arg(j), fm.wd if nd else None, fm.bias, labels,
+                        1.0 / B, fm.err, out=sets[j][0], ids_tm=tms[j] if tms else None)
+
+    def upd_dense(j):
+        buf, plan = sets[j]
+        ops.fm_bwd_apply_dense(plan, fm.table, buf['g'], buf['S'], _OPT[fm.opt], 0.0, fm.beta1, fm.beta2, fm.eps,
+                               nd_arg(j), buf['loss_rows'], fm.dp, fm.dm, fm.dv, fm.loss)
+
+    def fwd(j):
+        ids, dense, labels = batches[j]
+        ops.fm_fwd(fm.table, fm.toffs, ids, nd_arg(j), fm.wd if nd else None, fm.bias, labels, 1.0 / B, fm.err,
+                   out=sets[j][0])
+
+    def upd(j):
+        buf, plan = sets[j]
+        ops.fm_bwd_apply(plan, fm.table, buf['g'], buf['S'], _OPT[fm.opt], 0.0, fm.beta1, fm.beta2, fm.eps)
+
+    def dense_side(j):
+        buf = sets[j][0]
+        ops.fm_dense_step(buf['g'], nd_arg(j), buf['loss_rows'], fm.dp, fm.dm, fm.dv, 0.0, fm.beta1, fm.beta2, fm.eps,
+                          fm.loss)
+
     if fused:
         # the two launches the step is made of (timed without advancing the schedule / with step size 0)
-        add('launch 1: forward + per-table LDS sort',
-            lambda: ops.fm_fwd_sort(fm.table, fm.toffs, ids, fm.plan, nd_arg, fm.wd if nd else None, fm.bias, labels,
-                                    1.0 / B, fm.err, out=fm.buf, ids_tm=ids_tm), fwd_bytes + sort_bytes, 1)
-        add('launch 2: sparse update (segmented sum + fused %s) + dense side' % fm.opt,
-            lambda: ops.fm_bwd_apply_dense(fm.plan, fm.table, r['g'], r['S'], _OPT[fm.opt], 0.0, fm.beta1, fm.beta2,
-                                           fm.eps, nd_arg, r['loss_rows'], fm.dp, fm.dm, fm.dv, fm.loss),
+        add('launch 1: forward + per-table LDS sort', fwd_sort, fwd_bytes + sort_bytes, 1)
+        add('launch 2: sparse update (segmented sum + fused %s) + dense side' % fm.opt, upd_dense,
             bwd_bytes + B * (nd + 2) * 4, 1)
     # the members on their own
-    add('fm_fwd (gather+pool+interaction+loss)', lambda: fm.forward(ids, dense, labels), fwd_bytes, 1)
+    add('fm_fwd (gather+pool+interaction+loss)', fwd, fwd_bytes, 1)
     lds_sort = B <= 8192
     add('sort_by_row (%s)' % ('per-table LDS sort, 1 launch' if lds_sort else 'keygen + %d radix passes' % passes),
-        lambda: fm.plan.prepare(ids), sort_bytes, 1 if lds_sort else 1 + 3 * passes)
-    # the update stages are timed with lr = 0 so repeated calls do not walk the parameters away
-    add('fm_bwd_apply (segmented sum + fused %s)' % fm.opt,
-        lambda: ops.fm_bwd_apply(fm.plan, fm.table, r['g'], r['S'], _OPT[fm.opt], 0.0, fm.beta1, fm.beta2, fm.eps),
-        bwd_bytes, 1)
-    add('dense side (dwd/dbias + adam + mean loss)',
-        lambda: ops.fm_dense_step(r['g'], dense, r['loss_rows'], fm.dp, fm.dm, fm.dv, 0.0, fm.beta1, fm.beta2,
-                                  fm.eps, fm.loss), B * (nd + 2) * 4, 1)
+        lambda j: sets[j][1].prepare(batches[j][0]), sort_bytes, 1 if lds_sort else 1 + 3 * passes)
+    add('fm_bwd_apply (segmented sum + fused %s)' % fm.opt, upd, bwd_bytes, 1)
+    add('dense side (dwd/dbias + adam + mean loss)', dense_side, B * (nd + 2) * 4, 1)
+    for dst, src in zip((fm.table.rec, fm.dp, fm.dm, fm.dv, fm.sched), saved):
+        dst.copy_(src)
     return stages, U
 
 
+def host_cores():
+    """Threads the CPU baseline may use: the cores this process was given (OMP_NUM_THREADS is set to the
+    box's share on a shared machine), never more than the machine has."""
+    n = os.cpu_count() or 1
+    try:
+        share = int(os.environ.get('OMP_NUM_THREADS', '0'))
+    except ValueError:
+        share = 0
+    return max(1, min(n, share) if share > 0 else n)
+
+
 def cpu_baseline(args, rows, fm, batches):
-    """The numpy oracle's FM step (gather formulation) on a bounded sample of the same workload."""
+    """The numpy oracle's FM step (gather formulation; a B x 10 M one-hot matrix is infeasible) on the
+    SAME workload - same tables, same batches, same batch size - spread over every host core
+    (oracle.fm.train_step_mt: forward over sample shards, backward over tables).  10 warm-up steps,
+    then the median of --cpu-steps (default 50) timed steps (fewer only if 30 s run out)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import fm as ofm
     st = ofm.State.__new__(ofm.State)
     st.toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
@@ -201,18 +271,23 @@ def cpu_baseline(args, rows, fm, batches):
     elif args.opt == 'adagrad_rowwise':
         st.aV, st.aw = np.zeros(st.V.shape[0], np.float32), np.zeros(st.V.shape[0], np.float32)
     st.md, st.vd = np.zeros(len(st.wd) + 1, np.float32), np.zeros(len(st.wd) + 1, np.float32)
-    host = [(i.cpu().numpy(), d.cpu().numpy(), l.cpu().numpy()) for i, d, l in batches[:4]]
-    ofm.train_step(st, *host[0], lr=1e-3, dtype=np.float32)          # warm
-    t0 = time.perf_counter()
-    n = 0
-    while n < args.cpu_steps and time.perf_counter() - t0 < 30.0:
-        ofm.train_step(st, *host[n % len(host)], lr=1e-3, dtype=np.float32)
-        n += 1
-    dt = time.perf_counter() - t0
-    return dict(value=round(n * args.batch / dt, 1), unit='samples/s', cores=1, kind='port',
-                sample='%d steps of the same workload (batch %d, %d tables x dim %d) through the numpy oracle '
-                       '(gather formulation, fp32, single thread); host has %d cores'
-                       % (n, args.batch, len(rows), args.dim, os.cpu_count() or 0))
+    host = [(i.cpu().numpy(), d.cpu().numpy(), l.cpu().numpy()) for i, d, l in batches]
+    cores = host_cores()
+    times = []
+    with ThreadPoolExecutor(cores) as pool:
+        for k in range(10):
+            ofm.train_step_mt(st, *host[k % len(host)], pool, cores, lr=1e-3, dtype=np.float32)
+        t_end = time.perf_counter() + 30.0
+        while len(times) < args.cpu_steps and time.perf_counter() < t_end:
+            t0 = time.perf_counter()
+            ofm.train_step_mt(st, *host[len(times) % len(host)], pool, cores, lr=1e-3, dtype=np.float32)
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return dict(value=round(args.batch / med, 1), unit='samples/s', cores=cores, kind='port',
+                sample='median of %d steps after 10 warm-up steps of the same workload (the same %d batches of %d, %d '
+                       'tables x dim %d, %s) through the numpy oracle, gather formulation, fp32, %d threads (forward '
+                       'over sample shards, backward over tables); machine reports %d cores'
+                       % (len(times), len(host), args.batch, len(rows), args.dim, args.opt, cores, os.cpu_count() or 0))
 
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 peak of MI355X (MI355X_MICROARCH; the 5 PF headline includes 2:1 sparsity)
@@ -504,6 +579,61 @@ def bench_infer(args):
     return res
 
 
+def spawn_ranks(n, script=None, argv=None):
+    """`python bench.py --gpus N` without a launcher: start N child processes of this same command,
+    one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), from a parent that
+    makes no GPU call; relay rank 0's JSON line; non-zero exit status if any rank fails.  The
+    reference starts its own workers too (recommendation/train_job.py:41-63, 2 workers + 1 ps)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if have < n:
+        print("bench.py: --gpus %d but this machine has %d GPU(s)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] +
+                                      (sys.argv[1:] if argv is None else list(argv)), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = b''
+    failed = None
+    import selectors
+    sel = selectors.DefaultSelector()
+    sel.register(procs[0].stdout, selectors.EVENT_READ)
+    open_out = True
+    while True:
+        if open_out:
+            for key, _ in sel.select(timeout=0.2):
+                chunk = os.read(key.fileobj.fileno(), 65536)
+                if chunk:
+                    out += chunk
+                else:
+                    sel.unregister(key.fileobj)
+                    open_out = False
+        else:
+            time.sleep(0.2)
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad and failed is None:
+            failed = bad[0]
+            for p in procs:                       # the others would wait in a collective for ever
+                if p.poll() is None:
+                    p.kill()
+        if all(c is not None for c in codes) and not open_out:
+            break
+    lines = [l for l in out.decode(errors='replace').splitlines() if l.startswith('{')]
+    if lines:
+        print(lines[-1], flush=True)
+    if failed is not None:
+        return failed if failed > 0 else 1
+    return 0 if lines else 1
+
+
 def main():
     args = parse_args()
     if args.workload == 'infer':
@@ -517,13 +647,13 @@ def main():
         fn = {'dcn': bench_dcn, 'din': bench_din, 'embag': bench_embag}[args.workload]
         print(json.dumps(fn(args)))
         return
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher around us: start the ranks ourselves (this process has not touched the GPU yet)
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a launcher: python -m torch.distributed.run --nproc-per-node %d "
-                             "bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -595,24 +725,33 @@ def main():
                        'parallelism': 'single' if not sharded else 'rowwise-sharded tables x%d + replicated dense' % world},
         }
     if not sharded:
-        stages, U = stage_report(model, batches[0], args.stage_reps, args.idx_bits, tms[0] if tms else None)
+        stages, U = stage_report(model, batches, args.stage_reps, args.idx_bits, tms)
         hbm = [s for s in stages if s['name'].startswith(('fm_fwd', 'fm_bwd_apply'))]
         upd = [s for s in stages if s['name'].startswith('launch 2')]
         dom = upd[0] if upd else max(hbm, key=lambda s: s['ms'])
         result['stages'] = stages
-        result['unique_rows_per_step'] = U
+        result['stage_timing'] = ('HIP events on the launch stream; every stage cycles over the %d batches of the run, '
+                                  'each with its own prepared inputs (> 256 MiB of distinct lines between two uses of a '
+                                  'line)' % len(batches))
+        result['unique_rows_per_step'] = round(U, 1)
+        n_state = {'sgd': 0, 'adagrad_rowwise': 1.0 / args.dim, 'adam_tf': 2}[args.opt]
+        result['roofline_inputs'] = {'B': B, 'T': len(rows), 'D': args.dim, 'U': round(U, 1), 'id_bytes': args.idx_bits // 8,
+                                     'n_state': n_state, 'n_dense': 13}
         # HBM bytes per launch of that kernel from the PMC counters: they cannot be collected from inside
         # this process, so the committed measurement of this same workload is quoted (null for any other)
-        traffic = None
-        pmc_path = os.path.join(ROOT, 'profiles', 'r01_fm_b8192_pmc.json')
-        if upd and os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            k = pmc.get('kernels', {}).get('seg_sorted_kernel +dense')
-            if k and pmc.get('workload') == result['config']['workload'] and args.opt == 'adam_tf' \
-                    and args.dist == 'uniform':
-                traffic = k['hbm_bytes_per_launch']
+        traffic, traffic_source = None, None
+        for fname in ('r02_fm_b8192_pmc.json', 'r01_fm_b8192_pmc.json'):
+            pmc_path = os.path.join(ROOT, 'profiles', fname)
+            if upd and os.path.exists(pmc_path):
+                pmc = json.load(open(pmc_path))
+                k = pmc.get('kernels', {}).get('seg_sorted_kernel +dense')
+                if k and pmc.get('workload') == result['config']['workload'] and args.opt == 'adam_tf' \
+                        and args.dist == 'uniform':
+                    traffic, traffic_source = k['hbm_bytes_per_launch'], 'quoted profiles/%s' % fname
+                    break
         result['roofline'] = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS,
                               'unit': 'GB/s', 'frac': round(dom['gbs'] / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                              'traffic_source': traffic_source,
                               'alg_bytes_per_launch': dom['alg_bytes'], 'ms_per_launch': dom['ms']}
         emb = [s for s in hbm]
         result['embedding_hbm_gbs'] = round(sum(s['alg_bytes'] for s in emb) / sum(s['ms'] for s in emb) / 1e6, 1)

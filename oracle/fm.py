@@ -130,3 +130,67 @@ def synthetic_batch(B, rows_per_table, n_dense=13, seed=0, dist='uniform', alpha
     dense = rng.standard_normal((B, n_dense)).astype(np.float32)
     labels = (rng.random(B) < 0.25).astype(np.float32)
     return ids, dense, labels
+
+
+def train_step_mt(st, ids, dense, labels, pool, n_workers, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                  dtype=np.float64):
+    """train_step spread over the threads of ``pool`` (a concurrent.futures.ThreadPoolExecutor with
+    ``n_workers`` threads; numpy releases the interpreter lock inside its array loops): the forward
+    over contiguous shards of the samples, the sparse backward + update over the TABLES (the rows of
+    two tables are disjoint, and sorting a table's id column with a stable sort is the global stable
+    sort by (row, position) restricted to that table, so every run is summed in the order train_step
+    sums it).  Same results as train_step; it exists so that the CPU baseline can use every core."""
+    ids = np.asarray(ids)
+    B, T = ids.shape
+    toffs = np.asarray(st.toffs, dtype=np.int64)
+    bounds = np.linspace(0, B, n_workers + 1).astype(np.int64)
+
+    def fwd(i):
+        lo, hi = int(bounds[i]), int(bounds[i + 1])
+        if lo == hi:
+            return np.zeros(0, dtype), np.zeros((0, st.V.shape[1]), dtype)
+        z, S, _ = forward(st.V, st.w1, toffs, ids[lo:hi], None if dense is None else dense[lo:hi], st.wd, st.bias, dtype)
+        return z, S
+
+    parts = list(pool.map(fwd, range(n_workers)))
+    z = np.concatenate([p[0] for p in parts])
+    S = np.concatenate([p[1] for p in parts])
+    per, sig = bce_with_logits(z, np.asarray(labels, dtype=dtype))
+    g = ((sig - labels) / B).astype(dtype)
+    st.t += 1
+    lr_t, omb1, omb2 = emb.tf_adam_scalars(lr, beta1, beta2, st.t)
+    wdt = st.V.dtype
+
+    def bwd(t):
+        col = ids[:, t].astype(np.int64)
+        order = np.argsort(col, kind='stable')
+        uniq_ids, start = np.unique(col[order], return_index=True)
+        uniq = toffs[t] + uniq_ids
+        gs = g[order]
+        gsum = np.add.reduceat(gs, start)
+        acc = np.add.reduceat(gs[:, None] * S[order], start, axis=0)
+        dV = acc - st.V[uniq].astype(dtype) * gsum[:, None]
+        dw1 = gsum
+        if st.opt == 'sgd':
+            st.V[uniq] -= (lr * dV).astype(wdt)
+            st.w1[uniq] -= (lr * dw1).astype(wdt)
+        elif st.opt == 'adagrad_rowwise':
+            st.aV[uniq] += (dV * dV).mean(axis=1).astype(wdt)
+            st.V[uniq] -= (lr * dV / (np.sqrt(st.aV[uniq].astype(dtype)) + eps)[:, None]).astype(wdt)
+            st.aw[uniq] += (dw1 * dw1).astype(wdt)
+            st.w1[uniq] -= (lr * dw1 / (np.sqrt(st.aw[uniq].astype(dtype)) + eps)).astype(wdt)
+        else:
+            for w, m, v, gr in ((st.V, st.mV, st.vV, dV), (st.w1, st.mw, st.vw, dw1)):
+                nw, mm, vv = emb.adam_tf_update(w[uniq].astype(dtype), m[uniq].astype(dtype), v[uniq].astype(dtype),
+                                                gr, lr_t, omb1, omb2, eps)
+                m[uniq], v[uniq], w[uniq] = mm.astype(wdt), vv.astype(wdt), nw.astype(wdt)
+
+    list(pool.map(bwd, range(T)))
+    dwd = np.asarray(dense, dtype=dtype).T @ g if dense is not None else np.zeros(0, dtype)
+    gd = np.concatenate([dwd, [g.sum()]])
+    dp = np.concatenate([st.wd, [st.bias]]).astype(dtype)
+    dp, md, vd = emb.adam_tf_update(dp, st.md.astype(dtype), st.vd.astype(dtype), gd, lr_t, omb1, omb2, eps)
+    st.md, st.vd = md.astype(wdt), vd.astype(wdt)
+    st.wd = dp[:-1].astype(wdt)
+    st.bias = wdt.type(dp[-1])
+    return per.mean(), z

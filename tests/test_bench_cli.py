@@ -33,9 +33,48 @@ def test_defaults(monkeypatch):
     assert bench.parse_args().opt == 'adagrad_rowwise'
 
 
-def test_more_gpus_than_ranks_needs_the_launcher():
+def test_more_gpus_than_the_machine_has_is_refused():
+    """Without a launcher bench.py starts its own ranks, after checking that the GPUs are there."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this machine has the GPUs")
     r = _run('--gpus', '2', timeout=120)
-    assert r.returncode != 0 and 'torch.distributed.run' in r.stderr and r.stdout.strip() == ''
+    assert r.returncode != 0 and 'GPU' in r.stderr and r.stdout.strip() == ''
+
+
+def _spawn(tmp_path, monkeypatch, body):
+    sys.path.insert(0, ROOT)
+    import bench
+    import torch
+    script = tmp_path / 'rank.py'
+    script.write_text(body)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 2)
+    return bench.spawn_ranks(2, script=str(script), argv=['--x'])
+
+
+def test_self_launch_starts_one_process_per_rank_and_relays_rank_0(tmp_path, monkeypatch, capfd):
+    rc = _spawn(tmp_path, monkeypatch, """
+import json, os, sys
+assert sys.argv[1:] == ['--x'] and os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1'
+assert os.environ['RANK'] == os.environ['LOCAL_RANK'] and int(os.environ['MASTER_PORT']) > 0
+print('banner that is not JSON')
+print(json.dumps({'rank': int(os.environ['RANK'])}))
+""")
+    assert rc == 0
+    assert capfd.readouterr().out.strip() == '{"rank": 0}'
+
+
+def test_self_launch_fails_when_a_rank_fails_and_ends_the_others(tmp_path, monkeypatch, capfd):
+    import time
+    t0 = time.time()
+    rc = _spawn(tmp_path, monkeypatch, """
+import os, sys, time
+if os.environ['RANK'] == '1':
+    sys.exit(3)
+time.sleep(600)     # rank 0 would wait for ever in a collective
+""")
+    assert rc == 3 and time.time() - t0 < 60
+    assert capfd.readouterr().out.strip() == ''
 
 
 def _one_json_line(r):

@@ -74,3 +74,23 @@ def test_din_factored_first_layer_is_the_same_function():
     for k in g0:
         assert np.abs(g0[k] - g1[k]).max() <= 1e-12 * max(1.0, np.abs(g0[k]).max())
     assert np.array_equal(u0, u1) and np.abs(d0 - d1).max() <= 1e-12
+
+
+def test_threaded_fm_step_equals_the_plain_step():
+    """oracle.fm.train_step_mt (the all-cores CPU baseline) must give train_step's results."""
+    import copy
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import fm as ofm
+    rows = [50, 7, 3000, 3, 1000, 24]
+    for opt in ('sgd', 'adagrad_rowwise', 'adam_tf'):
+        a = ofm.State(rows, 16, 13, seed=1, opt=opt)
+        b = copy.deepcopy(a)
+        with ThreadPoolExecutor(3) as pool:
+            for step in range(3):
+                ids, dense, labels = ofm.synthetic_batch(500, rows, 13, seed=step, dist='zipf')
+                la, za = ofm.train_step(a, ids, dense, labels, lr=1e-2)
+                lb, zb = ofm.train_step_mt(b, ids, dense, labels, pool, 3, lr=1e-2)
+                assert abs(la - lb) <= 1e-12 * abs(la) and np.allclose(za, zb, rtol=1e-12, atol=0)
+        for name in ('V', 'w1', 'wd'):
+            assert np.allclose(getattr(a, name), getattr(b, name), rtol=1e-6, atol=1e-9), (opt, name)
+        assert abs(float(a.bias) - float(b.bias)) <= 1e-7
