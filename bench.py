@@ -54,6 +54,8 @@ def parse_args():
                          '(measured slower at world size 1: the extra stream hops cost more than the exchange they hide)')
     ap.add_argument('--din-full-rows', action='store_true',
                     help='DIN: materialise the full [q | k | q-k | q*k] rows instead of the factored first layer')
+    ap.add_argument('--no-prefetch-sort', action='store_true',
+                    help='single-GPU step: sort this batch\'s ids inside the step instead of beside the previous step')
     ap.add_argument('--ids-sample-major', action='store_true',
                     help='feed the single-GPU step ids as [B][T] only (default: also one [B] row per field)')
     ap.add_argument('--force-sharded', action='store_true',
@@ -167,6 +169,7 @@ def stage_report(fm, batches, reps, idx_bits, tms=None):
     D, nd = fm.dim, fm.n_dense
     ib = idx_bits // 8
     n_b = len(batches)
+    fm._buffers(batches[0][0])                 # the model's own loss / buffer set exist before the first step too
     saved = (fm.table.rec.clone(), fm.dp.clone(), fm.dm.clone(), fm.dv.clone(), fm.sched.clone())
     f32 = dict(dtype=torch.float32, device=fm.device)
     fused = fm.fused and B <= ops.fm_fwd_sort_max_batch()
@@ -692,7 +695,13 @@ def main():
     # one id tensor per field, stored field after field ([T][B]): the layout the two-launch step sorts fastest
     tms = [b[0].t().contiguous() for b in batches] if (not sharded and not args.ids_sample_major) else None
     kws = [dict(kw, ids_tm=tms[j]) if tms else kw for j in range(len(batches))]
-    for i in range(max(args.warmup, len(batches) if use_graph else 0)):   # every batch's graph captured before timing
+    prefetch_sort = not sharded and not args.no_prefetch_sort and B <= model._fused_max
+    if prefetch_sort:
+        # a training loop knows its next batch: its ids are sorted beside this step (the sort needs nothing else)
+        nb = len(batches)
+        kws = [dict(k, next_ids=batches[(j + 1) % nb][0], **({'next_ids_tm': tms[(j + 1) % nb]} if tms else {}))
+               for j, k in enumerate(kws)]
+    for i in range(max(args.warmup, 2 * len(batches) if use_graph else 0)):   # every batch's graph captured before timing
         model.train_step(*batches[i % len(batches)], **kws[i % len(batches)])
     barrier()
     t0 = time.perf_counter()
@@ -722,6 +731,8 @@ def main():
                        'id_bits': args.idx_bits, 'ids': args.dist,
                        'id_layout': 'field-major [T][B]' if tms else 'sample-major [B][T]', 'optimizer': args.opt,
                        'launch': 'hip graph replay' if use_graph else 'eager',
+                       'sort': ('next batch\'s ids sorted on a side stream beside this step' if prefetch_sort
+                                else 'inside the step'),
                        'parallelism': 'single' if not sharded else 'rowwise-sharded tables x%d + replicated dense' % world},
         }
     if not sharded:

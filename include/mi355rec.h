@@ -304,7 +304,10 @@ int mi_fm_dense_step(const float* g, const float* dense, int n_dense, int64_t B,
  * writes them.  Results are bit-identical to the separate calls.  ids_table_major != 0: ids is
  * [T][B], one contiguous array per field - how the reference feeds its features, one tensor per
  * field (r_model.py:42-51) - instead of [B][T]; a table's ids are then read as whole lines by its
- * sort workgroups (one line per id otherwise); perm keeps the positions b*T + t either way. */
+ * sort workgroups (one line per id otherwise); perm keeps the positions b*T + t either way.
+ * sorted_rows == perm == NULL: no sort in this launch (any B) - forward + schedule only, for a caller
+ * that sorted this batch's ids earlier, beside the previous step's update (mi_embag_bwd_prepare on a
+ * second stream: the sort needs nothing but the ids). */
 int mi_fm_fwd_sort_max_batch(void);
 int mi_fm_fwd_sort(const mi_fm_table* tab, const int64_t* table_offsets, int T, const void* ids,
                    int idx_bits, int64_t B, const float* dense, int n_dense, const float* wd,
@@ -312,6 +315,15 @@ int mi_fm_fwd_sort(const mi_fm_table* tab, const int64_t* table_offsets, int T, 
                    float* loss_rows, float* g, int32_t* err, int64_t total_rows,
                    uint32_t* sorted_rows, int32_t* perm, float* sched, float lr, float beta1,
                    float beta2, int ids_table_major, void* stream);
+
+/* The sort of mi_fm_fwd_sort on its own (one launch, every table sorted in the LDS of one to four
+ * CUs), for ids [B][T] or, with ids_table_major != 0, [T][B]; B <= mi_fm_fwd_sort_max_batch().  Same
+ * sorted_rows / perm, bit for bit.  The sort needs nothing but the ids, so a training loop that knows
+ * its next batch issues this on a second stream beside the CURRENT step's update and leaves the step
+ * itself with forward (mi_fm_fwd_sort without sort outputs) + update. */
+int mi_fm_sort_ids(const int64_t* table_offsets, int T, const void* ids, int idx_bits, int64_t B,
+                   int ids_table_major, int64_t total_rows, uint32_t* sorted_rows, int32_t* perm,
+                   void* stream);
 
 /* mi_fm_bwd_apply and mi_fm_dense_step in ONE launch (both start from g; neither needs the
  * other).  lr / lr_dev belong to the sparse side (optimizer `opt`), dense_lr_t / dense_lr_dev

@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmi355rec.so')
+# MI355REC_LIB: another build of the same library (kernel experiments); the default is the in-tree build
+LIB_PATH = os.environ.get('MI355REC_LIB') or os.path.join(_HERE, 'libmi355rec.so')
 
 MI_CHECK_RANGE, MI_CHECK_INCREASING, MI_CHECK_NONNEG = 1, 2, 4
 MI_IDERR_RANGE, MI_IDERR_ORDER, MI_IDERR_INTERNAL = 1, 2, 4
@@ -106,6 +107,7 @@ _SIGNATURES = {
     'mi_fm_fwd_sort_max_batch': (c_int, []),
     'mi_fm_fwd_sort': (c_int, [POINTER(FmTable), P, c_int, P, c_int, c_int64, P, c_int, P, P, P, c_float, P, P, P, P,
                                P, c_int64, P, P, P, c_float, c_float, c_float, c_int, P]),
+    'mi_fm_sort_ids': (c_int, [P, c_int, P, c_int, c_int64, c_int, c_int64, P, P, P]),
     'mi_fm_bwd_apply_dense': (c_int, [POINTER(BwdPlan), POINTER(FmTable), P, P, c_int, c_float, P, c_float, c_float,
                                       c_float, P, c_int, P, P, P, P, c_float, P, P, P]),
     'mi_parse_records': (c_int, [c_char_p, c_int64, c_int, c_int, c_int64, P, P, POINTER(c_int64), POINTER(c_int64)]),

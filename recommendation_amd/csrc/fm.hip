@@ -27,7 +27,9 @@ namespace {
 namespace {
 
 template <typename IDX, int DIM>
-__global__ __launch_bounds__(256) void fm_fwd_kernel(FmFwdArgs a) {
+__global__ __launch_bounds__(256) void fm_fwd_kernel(FmFwdArgs a, float* __restrict__ sched, float lr, float b1,
+                                                    float b2) {
+  if (sched && blockIdx.x == 0 && threadIdx.x == 0) adam_schedule_body(sched, lr, b1, b2);
   fm_fwd_body<IDX, DIM>(a, blockIdx.x, 256);
 }
 
@@ -50,6 +52,16 @@ __global__ __launch_bounds__(TS_THREADS) void fm_fwd_sort_kernel(FmFwdArgs a, in
   fm_fwd_body<IDX, DIM>(a, blockIdx.x - sort_blocks, TS_THREADS);
 }
 
+// The per-table sort on its own, for ids in either layout.
+template <typename IDX>
+__global__ __launch_bounds__(TS_THREADS) void fm_sort_kernel(const int64_t* __restrict__ toffs, int T,
+                                                            const void* __restrict__ ids, int B, int parts,
+                                                            uint32_t sentinel, uint32_t* __restrict__ sorted_rows,
+                                                            uint32_t* __restrict__ perm, int ids_tm) {
+  table_sort_body<IDX>(blockIdx.x / parts, blockIdx.x % parts, parts, toffs, T, ids, 1, B, sentinel, sorted_rows, perm,
+                       ids_tm != 0);
+}
+
 __global__ __launch_bounds__(FM_DENSE_THREADS) void fm_dense_kernel(FmDenseArgs a) {
   __shared__ float sh[FM_DENSE_THREADS];
   fm_dense_body(a, blockIdx.x, sh);
@@ -60,8 +72,8 @@ __global__ void adam_schedule_kernel(float* __restrict__ sched, float lr, float 
   adam_schedule_body(sched, lr, b1, b2);
 }
 
-// sorted_rows == NULL: the forward alone (256-thread workgroups).  Otherwise the fused
-// forward + per-table sort (+ optimizer schedule when sched != NULL) launch.
+// sorted_rows == NULL: the forward alone (256-thread workgroups; + optimizer schedule when sched != NULL).
+// Otherwise the fused forward + per-table sort (+ optimizer schedule when sched != NULL) launch.
 template <typename IDX>
 int launch_fm(const FmFwdArgs& a, uint32_t sentinel, uint32_t* sorted_rows, uint32_t* perm, float* sched, float lr,
               float b1, float b2, hipStream_t s) {
@@ -69,7 +81,8 @@ int launch_fm(const FmFwdArgs& a, uint32_t sentinel, uint32_t* sorted_rows, uint
   case D: {                                                                                                         \
     constexpr int G_ = (D / 4) > 16 ? (D / 4) : 16;                                                                 \
     if (!sorted_rows)                                                                                               \
-      hipLaunchKernelGGL((fm_fwd_kernel<IDX, D>), dim3((unsigned) mi_cdiv(a.B, 256 / G_)), dim3(256), 0, s, a);     \
+      hipLaunchKernelGGL((fm_fwd_kernel<IDX, D>), dim3((unsigned) mi_cdiv(a.B, 256 / G_)), dim3(256), 0, s, a,      \
+                         sched, lr, b1, b2);                                                                        \
     else {                                                                                                          \
       const int fwd_blocks_ = (int) mi_cdiv(a.B, TS_THREADS / G_);                                                  \
       const int parts_ = mi_table_sort_parts(a.T, a.B, fwd_blocks_);                                                \
@@ -171,13 +184,14 @@ extern "C" int mi_fm_fwd_sort(const mi_fm_table* tab, const int64_t* table_offse
   const char* who = "mi_fm_fwd_sort";
   const int rc = check_fwd(who, tab, table_offsets, T, ids, idx_bits, B, dense, n_dense, wd, S);
   if (rc) return rc;
-  MI_REQUIRE(sorted_rows && perm, "%s: null sort output", who);
-  if (B < 1 || B > TS_MAX) {
+  MI_REQUIRE((sorted_rows != nullptr) == (perm != nullptr), "%s: sorted_rows and perm go together", who);
+  if (sorted_rows && (B < 1 || B > TS_MAX)) {
     mi_set_error("%s: batch %lld outside 1..%d (one workgroup sorts a table in LDS); use mi_fm_fwd + "
                  "mi_embag_bwd_prepare", who, (long long) B, TS_MAX);
     return MI_ERR_UNSUPPORTED;
   }
-  if (total_rows < 1 || total_rows >= (int64_t) 0xFFFFFFFFll) {
+  if (B == 0) return MI_OK;
+  if (sorted_rows && (total_rows < 1 || total_rows >= (int64_t) 0xFFFFFFFFll)) {
     mi_set_error("%s: total_rows %lld does not fit the uint32 row key", who, (long long) total_rows);
     return MI_ERR_UNSUPPORTED;
   }
@@ -187,6 +201,34 @@ extern "C" int mi_fm_fwd_sort(const mi_fm_table* tab, const int64_t* table_offse
   uint32_t* pv = reinterpret_cast<uint32_t*>(perm);
   if (idx_bits == 32) return launch_fm<int32_t>(a, (uint32_t) total_rows, sorted_rows, pv, sched, lr, beta1, beta2, s);
   return launch_fm<int64_t>(a, (uint32_t) total_rows, sorted_rows, pv, sched, lr, beta1, beta2, s);
+}
+
+extern "C" int mi_fm_sort_ids(const int64_t* table_offsets, int T, const void* ids, int idx_bits, int64_t B,
+                              int ids_table_major, int64_t total_rows, uint32_t* sorted_rows, int32_t* perm,
+                              void* stream) {
+  const char* who = "mi_fm_sort_ids";
+  MI_REQUIRE(table_offsets && ids && sorted_rows && perm, "%s: null pointer", who);
+  MI_REQUIRE(T >= 1 && (idx_bits == 32 || idx_bits == 64), "%s: bad T / idx_bits", who);
+  if (B < 1 || B > TS_MAX) {
+    mi_set_error("%s: batch %lld outside 1..%d (one workgroup sorts a table in LDS); use mi_embag_bwd_prepare", who,
+                 (long long) B, TS_MAX);
+    return MI_ERR_UNSUPPORTED;
+  }
+  if (total_rows < 1 || total_rows >= (int64_t) 0xFFFFFFFFll) {
+    mi_set_error("%s: total_rows %lld does not fit the uint32 row key", who, (long long) total_rows);
+    return MI_ERR_UNSUPPORTED;
+  }
+  const int parts = mi_table_sort_parts(T, (int) B, 0);
+  uint32_t* pv = reinterpret_cast<uint32_t*>(perm);
+  hipStream_t s = (hipStream_t) stream;
+  if (idx_bits == 32)
+    hipLaunchKernelGGL(fm_sort_kernel<int32_t>, dim3(T * parts), dim3(TS_THREADS), 0, s, table_offsets, T, ids, (int) B,
+                       parts, (uint32_t) total_rows, sorted_rows, pv, ids_table_major ? 1 : 0);
+  else
+    hipLaunchKernelGGL(fm_sort_kernel<int64_t>, dim3(T * parts), dim3(TS_THREADS), 0, s, table_offsets, T, ids, (int) B,
+                       parts, (uint32_t) total_rows, sorted_rows, pv, ids_table_major ? 1 : 0);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
 }
 
 extern "C" int mi_adam_schedule_step(float* sched, float lr, float beta1, float beta2, void* stream) {

@@ -147,13 +147,41 @@ constexpr int FM_DENSE_THREADS = 256;
 // loss_ld floats apart (1, n_dense, 1 for plain arrays).  All FM_DENSE_THREADS threads take part.
 __device__ __forceinline__ void fm_dense_body(const FmDenseArgs& a, int j, float* sh /* FM_DENSE_THREADS floats */) {
   constexpr int NT = FM_DENSE_THREADS;
+  // 16 samples per thread per round, all their loads requested before the first is used (a plain
+  // loop is a chain of dependent round trips, 32 of them at batch 8192; this is two - more in flight
+  // would cost the fused update launch, which this body shares registers with, a wave per SIMD); the
+  // additions keep the order b = t, t+256, ... of that loop, so the sums are the same bits.
+  constexpr int UR = 16;
+  // what the closing optimizer step reads, requested now so that it does not cost a round trip of its own
+  float pm = 0.f, pv = 0.f, pp = 0.f, plr = a.lr_t;
+  if (threadIdx.x == 0 && j <= a.n_dense && a.dp) {
+    pm = a.dm[j];
+    pv = a.dv[j];
+    pp = a.dp[j];
+    if (a.lr_dev) plr = a.lr_dev[0];
+  }
   float acc = 0.f;
-  if (j < a.n_dense) {
-    for (int64_t b = threadIdx.x; b < a.B; b += NT) acc = fmaf(a.g[b * a.g_ld], a.dense[b * a.dense_ld + j], acc);
-  } else if (j == a.n_dense) {
-    for (int64_t b = threadIdx.x; b < a.B; b += NT) acc += a.g[b * a.g_ld];
-  } else {
-    for (int64_t b = threadIdx.x; b < a.B; b += NT) acc += a.loss_rows[b * a.loss_ld];
+  for (int64_t b0 = threadIdx.x; b0 < a.B; b0 += (int64_t) UR * NT) {
+    float x[UR], y[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int64_t b = b0 + (int64_t) u * NT;
+      const int64_t bs = b < a.B ? b : b0;
+      if (j < a.n_dense) {
+        x[u] = a.g[bs * a.g_ld];
+        y[u] = a.dense[bs * a.dense_ld + j];
+      } else if (j == a.n_dense) {
+        x[u] = a.g[bs * a.g_ld];
+        y[u] = 1.0f;
+      } else {
+        x[u] = a.loss_rows[bs * a.loss_ld];
+        y[u] = 1.0f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      if (b0 + (int64_t) u * NT < a.B) acc = (j < a.n_dense) ? fmaf(x[u], y[u], acc) : acc + x[u];
+    }
   }
   sh[threadIdx.x] = acc;
   __syncthreads();
@@ -169,11 +197,11 @@ __device__ __forceinline__ void fm_dense_body(const FmDenseArgs& a, int j, float
   }
   if (a.grad_out) a.grad_out[j] = tot;
   if (a.dp) {
-    const float mi = a.dm[j] + (tot - a.dm[j]) * (1.0f - a.b1);
-    const float vi = a.dv[j] + (tot * tot - a.dv[j]) * (1.0f - a.b2);
+    const float mi = pm + (tot - pm) * (1.0f - a.b1);
+    const float vi = pv + (tot * tot - pv) * (1.0f - a.b2);
     a.dm[j] = mi;
     a.dv[j] = vi;
-    a.dp[j] -= (mi * (a.lr_dev ? a.lr_dev[0] : a.lr_t)) / (sqrtf(vi) + a.eps);
+    a.dp[j] = pp - (mi * plr) / (sqrtf(vi) + a.eps);
   }
 }
 

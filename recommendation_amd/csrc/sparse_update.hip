@@ -27,7 +27,16 @@
 
 namespace {
 
-constexpr int WAVE_MAX = 256;   // one wave sums runs up to this; longer runs are queued for a workgroup
+#ifndef MI_WAVE_MAX
+#define MI_WAVE_MAX 256
+#endif
+#ifndef MI_SPLIT_GATE
+#define MI_SPLIT_GATE 2
+#endif
+#ifndef MI_SPLIT_MIN
+#define MI_SPLIT_MIN (4 * 1024)
+#endif
+constexpr int WAVE_MAX = MI_WAVE_MAX;   // one wave sums runs up to this; longer runs are queued for a workgroup
 constexpr int UBLOCK = 256;
 constexpr int LONG_GRID = 512;
 
@@ -165,6 +174,14 @@ __device__ __forceinline__ void opt_load(const float* w, const float* s0, const 
   }
 }
 
+// a / b and sqrt(x) through the hardware's 1-ulp reciprocal and square root (v_rcp_f32, v_sqrt_f32): the
+// correctly rounded forms the compiler emits otherwise are ~10 instructions each, and with four columns
+// per lane and a row per lane group they were most of the kernel's vector instructions.  1 ulp is 6e-8
+// relative on the step, far inside the 1e-5 bar; every path uses the same forms, so results stay
+// bitwise reproducible and equal between launch variants.
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 template <int OPT, int VEC>
 __device__ __forceinline__ void opt_finish(float* w, float* s0, float* s1, int dim, int c, int lanes, const float* g,
                                            const OptArgs& a, OptRegs<OPT, VEC>& r) {
@@ -178,7 +195,7 @@ __device__ __forceinline__ void opt_finish(float* w, float* s0, float* s1, int d
     for (int k = 0; k < VEC; ++k) ss += g[k] * g[k];
     ss = group_sum(ss, lanes);
     const float st = r.s0[0] + ss / (float) dim;
-    const float inv = a.step() / (sqrtf(st) + a.eps);
+    const float inv = fast_div(a.step(), fast_sqrt(st) + a.eps);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) r.w[k] -= inv * g[k];
     if (c == 0) s0[0] = st;
@@ -188,7 +205,7 @@ __device__ __forceinline__ void opt_finish(float* w, float* s0, float* s1, int d
       // the three statements of TensorFlow's ApplyAdam kernel, (1 - beta) formed in fp32 as there
       r.s0[k] += (g[k] - r.s0[k]) * (1.0f - a.beta1);
       r.s1[k] += (g[k] * g[k] - r.s1[k]) * (1.0f - a.beta2);
-      r.w[k] -= (r.s0[k] * a.step()) / (sqrtf(r.s1[k]) + a.eps);
+      r.w[k] -= fast_div(r.s0[k] * a.step(), fast_sqrt(r.s1[k]) + a.eps);
     }
     stv<VEC>(s0 + off, r.s0);
     stv<VEC>(s1 + off, r.s1);
@@ -437,6 +454,32 @@ __device__ __forceinline__ void group_run(const PlanDev& pl, const Src& src, con
   upd.template finish<VEC>((int64_t) row, c, lanes, regs, acc, sc);
 }
 
+// The same for a run of up to 4 entries whose permutation entries the caller already holds (p[q] for
+// q < len; the others may be anything valid): the row's state and the gradient sources are requested
+// together, one memory round trip instead of two.
+template <int VEC, class Src, class Upd>
+__device__ __forceinline__ void group_run4_pre(const PlanDev& pl, const Src& src, const Upd& upd, int lanes, int c,
+                                               const int* p, int len, uint32_t row) {
+  typename Upd::template Regs<VEC> regs;
+  upd.template load<VEC>((int64_t) row, c, regs);
+  float v[4][VEC], s[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) src.template load<VEC>(pl, p[q], c, v[q], s[q]);
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+  float sc = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q < len) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += v[q][k];
+      sc += s[q];
+    }
+  }
+  upd.template finish<VEC>((int64_t) row, c, lanes, regs, acc, sc);
+}
+
 constexpr int GROUP_MAX = 16;  // a lane group sums runs up to this itself
 
 // The runs some lane groups of a wave could not take (more than GROUP_MAX entries, or end not
@@ -569,8 +612,95 @@ __device__ __forceinline__ void block_run(const PlanDev& pl, const Src& src, con
 // WAVE_MAX (entry i heads one iff its row differs from entry i-1's and equals entry
 // i+WAVE_MAX's) and sums those with all its threads.  They are dispatched first and work beside
 // the short runs instead of after them; nothing is queued, no atomics on global memory.
+// Narrow rows (LANES = dim / VEC <= 4 lanes per row): one wave's 64 sorted entries with EVERYTHING
+// requested up front.  After the wave's rows and permutation entries (one coalesced round trip) the
+// heads are ranked by a ballot, every lane group learns the (up to LANES) runs it owns from a
+// wave-private LDS table, and requests in one go the optimizer state of those rows and the gradient
+// sources of its LANES entries (entry e is fetched by group e % G whoever owns its run).  The
+// sources pass through wave-private LDS, where the owner of a run adds its entries in sorted order -
+// the order group_sum4 / group_sum16 use, so runs of up to 16 entries keep their bits - and applies
+// the update.  Two dependent memory round trips per wave however the 64 entries split into runs,
+// and no per-round search for the k-th head.  The one run that may continue past the wave's last
+// entry is left to wave_pending as before.
+// cs: 64 * (LANES*VEC + 4) floats, ss: 64 floats, hp: 65 ints - this wave's own.
+template <int VEC, int LANES, class Src, class Upd>
+__device__ __forceinline__ void short_wave_lds(const PlanDev& pl, const Src& src, const Upd& upd, int base,
+                                               uint32_t key, int perm_reg, unsigned long long hm,
+                                               uint32_t after_wave, uint32_t sentinel, float* __restrict__ cs,
+                                               float* __restrict__ ss, int* __restrict__ hp) {
+  constexpr int G = 64 / LANES, R = LANES, STR = LANES * VEC + 4;
+  const int lane = threadIdx.x & 63, g = lane / LANES, c = lane - g * LANES;
+  const int nheads = __popcll(hm);
+  if (nheads == 0) return;  // all 64 entries continue a run that started earlier: its opener's job (uniform)
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  if ((hm >> lane) & 1ull) hp[__popcll(hm & lt)] = lane;
+  if (lane == 0) hp[nheads] = 64;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int pos[R], len[R];
+  uint32_t row[R];
+  bool have[R];
+  bool pending = false;
+  int pend_beg = 0;
+  uint32_t pend_row = 0;
+  typename Upd::template Regs<VEC> regs[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int k = q * G + g;
+    const bool in = k < nheads;
+    pos[q] = in ? hp[k] : 0;
+    len[q] = in ? hp[k + 1] - pos[q] : 0;
+    row[q] = (uint32_t) __shfl((int) key, pos[q], 64);
+    have[q] = in && row[q] != sentinel;
+    if (have[q] && k == nheads - 1 && base + 64 < pl.n && after_wave == row[q]) {  // continues in the next wave
+      have[q] = false;
+      pending = (c == 0);
+      pend_beg = base + pos[q];
+      pend_row = row[q];
+    }
+    // unconditional (a branch around a load makes the compiler wait for all outstanding loads where the
+    // paths join): a slot without a run reads row 0, which exists
+    upd.template load<VEC>(have[q] ? (int64_t) row[q] : 0, c, regs[q]);
+  }
+  float v[R][VEC], sv[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int p = __shfl(perm_reg, r * G + g, 64);
+    src.template load<VEC>(pl, p, c, v[r], sv[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = r * G + g;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) cs[e * STR + c * VEC + k] = v[r][k];
+    if (c == 0) ss[e] = sv[r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    if (have[q]) {
+      float acc[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+      float sc = 0.f;
+      for (int j = 0; j < len[q]; ++j) {
+        const int e = pos[q] + j;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += cs[e * STR + c * VEC + k];
+        sc += ss[e];
+      }
+      upd.template finish<VEC>((int64_t) row[q], c, LANES, regs[q], acc, sc);
+    }
+  }
+  wave_pending<VEC>(pl, src, upd, LANES, pending, pend_beg, -1, pend_row, pend_beg, false);
+}
+
 constexpr int LONG_CHUNK = 1024;
-constexpr int SPLIT_MIN = 4 * LONG_CHUNK;  // runs longer than this are summed piecewise by several workgroups
+constexpr int SPLIT_MIN = MI_SPLIT_MIN;  // runs longer than this are summed piecewise by several workgroups
+constexpr int WAVE_RUN_MAX = 1024;  // a long-run workgroup leaves runs up to this to single waves
 constexpr int LONG_CAP = LONG_CHUNK / (WAVE_MAX + 1) + 2;  // heads of long runs are more than WAVE_MAX apart
 
 //
@@ -593,9 +723,13 @@ struct FmDenseFinalExtra {
 };
 static_assert(FM_DENSE_THREADS == UBLOCK, "the dense side runs in workgroups of the sparse update's size");
 
-template <int VEC, bool SPLIT, class Src, class Upd, class Extra>
-__global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src, Upd upd, int lanes, int groups,
+// LP: lanes per row when that is 1, 2 or 4 (rows of up to 16 floats: only the LDS path for the short runs
+// is compiled, which keeps the kernel under 128 vector registers - four waves per SIMD instead of
+// three), 0 for any other width (lanes is then read from the argument).
+template <int VEC, bool SPLIT, int LP, class Src, class Upd, class Extra>
+__global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src, Upd upd, int lanes_arg, int groups,
                                                            int long_blocks, Extra extra) {
+  const int lanes = LP > 0 ? LP : lanes_arg;
   if (pl.n_dev) pl.n = min(pl.n, pl.n_dev[0]);
   const uint32_t* keys = pl.sorted_rows;
   const uint32_t sentinel = pl.sentinel;
@@ -623,14 +757,30 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
       k_far_l = lo >= SPLIT_MIN / 2 ? keys[lo - SPLIT_MIN / 2] : ~k_lo;
       k_far_r = lo + SPLIT_MIN / 2 < pl.n ? keys[lo + SPLIT_MIN / 2] : ~k_lo;
     }
-    for (int i = lo + threadIdx.x; i < hi; i += UBLOCK) {
-      if (i + WAVE_MAX >= pl.n) break;
-      const uint32_t key = keys[i];
-      if (key == sentinel || keys[i + WAVE_MAX] != key) continue;
-      if (i > 0 && keys[i - 1] == key) continue;
-      // bit 30 marks a run of more than SPLIT_MIN entries (positions are below 2^30: see the host check)
-      const bool big = SPLIT && i + SPLIT_MIN < pl.n && keys[i + SPLIT_MIN] == key;
-      sh_heads[atomicAdd(&sh_n, 1)] = i | (big ? (1 << 30) : 0);
+    {
+      // every key this scan looks at is requested before any is examined (one memory round trip for the
+      // chunk instead of up to three dependent ones per 256 entries)
+      constexpr int IT = LONG_CHUNK / UBLOCK;
+      uint32_t k0[IT], k1[IT], km[IT], kb[IT];
+      bool ok[IT];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int i = lo + it * UBLOCK + (int) threadIdx.x;
+        ok[it] = i < hi && i + WAVE_MAX < pl.n;
+        k0[it] = keys[ok[it] ? i : lo];
+        k1[it] = keys[ok[it] ? i + WAVE_MAX : lo];
+        km[it] = keys[ok[it] && i > 0 ? i - 1 : lo];
+        kb[it] = SPLIT ? keys[ok[it] && i + SPLIT_MIN < pl.n ? i + SPLIT_MIN : lo] : 0u;
+      }
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int i = lo + it * UBLOCK + (int) threadIdx.x;
+        if (!ok[it] || k0[it] == sentinel || k1[it] != k0[it]) continue;
+        if (i > 0 && km[it] == k0[it]) continue;
+        // bit 30 marks a run of more than SPLIT_MIN entries (positions are below 2^30: see the host check)
+        const bool big = SPLIT && i + SPLIT_MIN < pl.n && kb[it] == k0[it];
+        sh_heads[atomicAdd(&sh_n, 1)] = i | (big ? (1 << 30) : 0);
+      }
     }
     __syncthreads();
     const int nh = sh_n;
@@ -640,6 +790,29 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
         int y = x - 1;
         for (; y >= 0 && (sh_heads[y] & ~(1 << 30)) > (v & ~(1 << 30)); --y) sh_heads[y + 1] = sh_heads[y];
         sh_heads[y + 1] = v;
+      }
+    }
+    __syncthreads();
+    // Heads of runs of up to WAVE_RUN_MAX entries are dealt to the workgroup's waves round robin, each
+    // summed by its wave alone: a chunk that holds several such heads (a table of 27 rows at batch 8192:
+    // runs of ~300, three or four heads per chunk) works on them side by side instead of one after
+    // the other with all its threads and a dozen barriers each.
+    __shared__ int sh_done[LONG_CAP], sh_ends[LONG_CAP];
+    for (int h = threadIdx.x >> 6; h < nh; h += UBLOCK / 64) {  // uniform over the wave
+      const int hv = sh_heads[h];
+      int done = 0, hend_out = -1;
+      if (!(hv >> 30)) {
+        const uint32_t hrow = keys[hv];
+        const int hend = run_end_wave(keys, pl.n, hv, hrow);
+        hend_out = hend;  // kept for the workgroup phase below: no second search
+        if (hend - hv <= WAVE_RUN_MAX) {
+          wave_run<VEC>(pl, src, upd, lanes, hv, hend, hrow);
+          done = 1;
+        }
+      }
+      if ((threadIdx.x & 63) == 0) {
+        sh_done[h] = done;
+        sh_ends[h] = hend_out;
       }
     }
     __syncthreads();
@@ -663,10 +836,11 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
         }
         piece_lo = lo;
       } else {
+        if (sh_done[h]) continue;  // summed by one of the waves above
         piece_lo = sh_heads[h] & ~(1 << 30);
         row = keys[piece_lo];
         if (!SPLIT || !(sh_heads[h] >> 30)) {  // the whole run is this workgroup's
-          block_run<VEC>(pl, src, upd, lanes, groups, piece_lo, -1, row, red, reds, &sh_end);
+          block_run<VEC>(pl, src, upd, lanes, groups, piece_lo, sh_ends[h], row, red, reds, &sh_end);
           continue;
         }
         if (threadIdx.x == 0) sh_span[0] = piece_lo;
@@ -732,6 +906,9 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
   if (base >= pl.n) return;  // uniform over the wave
   const int i = base + lane;
   const uint32_t key = i < pl.n ? keys[i] : sentinel;
+  // the wave's 64 permutation entries, requested with its rows (one coalesced load): a run that closes
+  // inside the wave gets its entries by shuffle instead of a dependent load per run
+  const int perm_reg = pl.perm[i < pl.n ? i : base];
   uint32_t edge = sentinel;  // lane 0: the row before the wave's first; lane 63: the row after its last
   if (lane == 0 && base > 0) edge = keys[base - 1];
   if (lane == 63 && base + 64 < pl.n) edge = keys[base + 64];
@@ -744,6 +921,14 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
   const bool head = key != prev;
   const unsigned long long hm = __ballot(head);
   const int nheads = __popcll(hm);
+  if constexpr (LP > 0) {
+    __shared__ float lds_cs[UBLOCK / 64][64 * (LP * VEC + 4)];
+    __shared__ float lds_ss[UBLOCK / 64][64];
+    __shared__ int lds_hp[UBLOCK / 64][65];
+    const int w = threadIdx.x >> 6;
+    short_wave_lds<VEC, LP>(pl, src, upd, base, key, perm_reg, hm, after_wave, sentinel, lds_cs[w], lds_ss[w], lds_hp[w]);
+    return;
+  }
   const int G = 64 / lanes, g = lane / lanes, c = lane - g * lanes;
   if constexpr (Src::kBatchSingles && Upd::kBatchSingles > 0) {
     // A full wave whose 64 entries are 64 different rows, none of them padding and the last one not
@@ -793,9 +978,13 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
     const bool have = k < nheads && row != sentinel;
     const bool open = have && !later && base + 64 < pl.n && after_wave == row;  // continues in the next wave
     const int len = endpos - pos;
+    int p4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p4[q] = __shfl(perm_reg, pos + q < 64 ? pos + q : pos, 64);  // every lane takes part
     bool pending = false;
     if (have) {
-      if (!open && len <= GROUP_MAX) group_run<VEC>(pl, src, upd, lanes, c, base + pos, len, row);
+      if (!open && len <= 4) group_run4_pre<VEC>(pl, src, upd, lanes, c, p4, len, row);
+      else if (!open && len <= GROUP_MAX) group_run<VEC>(pl, src, upd, lanes, c, base + pos, len, row);
       else pending = (c == 0);
     }
     wave_pending<VEC>(pl, src, upd, lanes, pending, base + pos, open ? -1 : base + endpos, row, base + pos, false);
@@ -935,17 +1124,25 @@ int run_segments(const mi_bwd_plan* plan, const PlanDev& pl, const Src& src, con
     // entries: with fixed-width bags a row gets at most the n_entries / T entries of its table
     const int64_t per_table = plan->offsets ? plan->n_entries : plan->n_entries / plan->T;
     pls.split = (int64_t) long_blocks * (1 + 2 * (g.lanes * g.vec + 1)) <= plan->n_entries &&
-                        plan->n_entries < ((int64_t) 1 << 30) && per_table > 2 * SPLIT_MIN
+                        plan->n_entries < ((int64_t) 1 << 30) && per_table > MI_SPLIT_GATE * SPLIT_MIN
                     ? 1 : 0;
     const unsigned grid = (unsigned) (extra.blocks + long_blocks + mi_cdiv(plan->n_entries, UBLOCK));
-#define SEG_LAUNCH(V, SP)                                                                                              \
-  hipLaunchKernelGGL((seg_sorted_kernel<V, SP, Src, Upd, Extra>), dim3(grid), dim3(UBLOCK), 0, s, pls, src, upd, g.lanes, \
-                     g.gpb, long_blocks, extra)
+#define SEG_LAUNCH(V, SP, LP)                                                                                          \
+  hipLaunchKernelGGL((seg_sorted_kernel<V, SP, LP, Src, Upd, Extra>), dim3(grid), dim3(UBLOCK), 0, s, pls, src, upd,   \
+                     g.lanes, g.gpb, long_blocks, extra)
+#define SEG_LANES(V, SP)                                                                                               \
+  switch (g.lanes) {                                                                                                   \
+    case 1: SEG_LAUNCH(V, SP, 1); break;                                                                               \
+    case 2: SEG_LAUNCH(V, SP, 2); break;                                                                               \
+    case 4: SEG_LAUNCH(V, SP, 4); break;                                                                               \
+    default: SEG_LAUNCH(V, SP, 0); break;                                                                              \
+  }
     if (g.vec == 4) {
-      if (pls.split) SEG_LAUNCH(4, true); else SEG_LAUNCH(4, false);
+      if (pls.split) { SEG_LANES(4, true) } else { SEG_LANES(4, false) }
     } else {
-      if (pls.split) SEG_LAUNCH(1, true); else SEG_LAUNCH(1, false);
+      if (pls.split) { SEG_LANES(1, true) } else { SEG_LANES(1, false) }
     }
+#undef SEG_LANES
 #undef SEG_LAUNCH
     MI_LAUNCH_CHECK();
     return MI_OK;

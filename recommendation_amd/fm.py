@@ -59,6 +59,8 @@ class FactorizationMachine(object):
         self._bufsets = {}                     # (B, id dtype) -> (buffers, loss, plan); kept, so captured graphs stay valid
         self._graphs = {}
         self._side = None
+        self._prefetched = None                # (address, B, dtype) of the ids whose sort the last step left behind
+        self._cur = 0                          # which of the two plans of a buffer set holds it
         self.fused = True                      # set False to run the step as five separate launches
         self._fused_max = ops.fm_fwd_sort_max_batch()
 
@@ -103,8 +105,12 @@ class FactorizationMachine(object):
                            loss_rows=torch.empty((B,), **f32), g=torch.empty((B,), **f32))
                 loss = torch.empty((1,), **f32)
                 plan = ops.SortedPlan(self.toffs, self.T, self.total_rows, ids, bag_len=1, runs=False)
-                self._bufsets[key] = (buf, loss, plan)
-            self.buf, self.loss, self.plan = self._bufsets[key]
+                # a second plan, so that the NEXT batch's ids can be sorted while this batch's plan is in use
+                plan2 = ops.SortedPlan(self.toffs, self.T, self.total_rows, ids, bag_len=1, runs=False) \
+                    if B <= self._fused_max else None
+                self._bufsets[key] = (buf, loss, [plan, plan2])
+            self.buf, self.loss, self._plans = self._bufsets[key]
+            self.plan = self._plans[0]
             self._buf_B = key
         return self.buf
 
@@ -115,6 +121,31 @@ class FactorizationMachine(object):
         B = ids.shape[0]
         return ops.fm_fwd(self.table, self.toffs, ids, dense if self.n_dense else None,
                           self.wd if self.n_dense else None, self.bias, labels, 1.0 / B, self.err, out=buf)
+
+    def _step_prefetched(self, ids, dense, labels, cur, next_ids, next_ids_tm, sorted_now, ids_tm):
+        """The step with the sort off its critical path: the sort needs nothing but ids, so the NEXT
+        batch's ids are sorted on a side stream while this batch's forward and update run; the step
+        itself is forward (+ schedule) and update (+ dense side).  ``cur``: which of the two plans
+        holds this batch's sort; ``sorted_now``: it does not yet (first step, or the caller passed
+        other ids than it announced), so this batch is sorted here first."""
+        main = torch.cuda.current_stream()
+        adam = self.opt == 'adam_tf'
+        B = ids.shape[0]
+        plan, nxt = self._plans[cur], self._plans[cur ^ 1]
+        if sorted_now:
+            ops.fm_sort_ids(self.toffs, ids, plan, ids_tm=ids_tm)
+        side = self._side[0]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.fm_sort_ids(self.toffs, next_ids, nxt, ids_tm=next_ids_tm)
+        r = ops.fm_fwd_sort(self.table, self.toffs, ids, None, dense if self.n_dense else None,
+                            self.wd if self.n_dense else None, self.bias, labels, 1.0 / B, self.err,
+                            out=self.buf, sched=self.sched, lr=self.lr, beta1=self.beta1, beta2=self.beta2, ids_tm=ids_tm)
+        ops.fm_bwd_apply_dense(plan, self.table, r['g'], r['S'], _OPT[self.opt], self.lr, self.beta1, self.beta2,
+                               self.eps, dense if self.n_dense else None, r['loss_rows'], self.dp, self.dm, self.dv,
+                               self.loss, lr_dev=self.sched if adam else None, dense_lr_dev=self.sched)
+        main.wait_stream(side)
+        self.plan = plan
 
     def _step_body(self, ids, dense, labels, streams=None, ids_tm=None):
         """The launches of one step.  With ``streams`` (two side streams, used under graph capture)
@@ -159,17 +190,39 @@ class FactorizationMachine(object):
         else:
             dense_side()
 
-    def train_step(self, ids, dense, labels, check_ids=False, graph=False, ids_tm=None):
+    def train_step(self, ids, dense, labels, check_ids=False, graph=False, ids_tm=None, next_ids=None,
+                   next_ids_tm=None):
         """One pass of the hot path; returns the mean loss as a 1-element device tensor.
         ``graph=True`` replays a HIP graph of the step captured on first use for these input
         buffers (the inputs must stay at the same addresses; their contents may change).
         ``ids_tm``: the same ids as a contiguous [T][B] tensor (one row per field, the way the
         reference feeds one tensor per feature); the two-launch step then reads that layout, which
-        lets a table's sort load its ids as whole lines."""
+        lets a table's sort load its ids as whole lines.
+        ``next_ids`` (+ ``next_ids_tm``): the ids of the batch the NEXT call will train on, same
+        shape.  The sort by row needs nothing but ids, so it is taken off this step's critical path:
+        the next batch is sorted on a side stream beside this step's forward and update, and the next
+        call (which must pass that same tensor, contents unchanged) finds its sort done.  Results are
+        bit-identical to the step without ``next_ids``."""
         self._buffers(ids)
+        B = ids.shape[0]
+        pre = next_ids is not None and self.fused and B <= self._fused_max
+        if pre:
+            if tuple(next_ids.shape) != tuple(ids.shape) or next_ids.dtype != ids.dtype:
+                raise ops.MiError("train_step: next_ids must have the shape and dtype of ids")
+            if self._side is None:
+                self._side = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+            want = (ids.data_ptr(), B, ids.dtype)
+            sorted_now = self._prefetched != want
+            cur = self._cur if not sorted_now else 0
+            self._prefetched = (next_ids.data_ptr(), B, ids.dtype)
+            self._cur = cur ^ 1
+        else:
+            self._prefetched = None
         if graph:
             key = (ids.data_ptr(), dense.data_ptr(), labels.data_ptr(), ids.shape[0], ids.dtype,
                    ids_tm.data_ptr() if ids_tm is not None else 0)
+            if pre:
+                key += (next_ids.data_ptr(), next_ids_tm.data_ptr() if next_ids_tm is not None else 0, cur, sorted_now)
             g = self._graphs.get(key)
             if g is None:
                 if self._side is None:
@@ -177,9 +230,16 @@ class FactorizationMachine(object):
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._step_body(ids, dense, labels, streams=self._side, ids_tm=ids_tm)
+                    if pre:
+                        self._step_prefetched(ids, dense, labels, cur, next_ids, next_ids_tm, sorted_now, ids_tm)
+                    else:
+                        self._step_body(ids, dense, labels, streams=self._side, ids_tm=ids_tm)
                 self._graphs[key] = g
             g.replay()
+            if pre:
+                self.plan = self._plans[cur]
+        elif pre:
+            self._step_prefetched(ids, dense, labels, cur, next_ids, next_ids_tm, sorted_now, ids_tm)
         else:
             self._step_body(ids, dense, labels, ids_tm=ids_tm)
         self.steps += 1

@@ -421,10 +421,11 @@ def fm_fwd_sort(table, toffs, ids, plan, dense=None, wd=None, bias=None, labels=
                 sched=None, lr=0.0, beta1=0.9, beta2=0.999, ids_tm=None):
     """fm_fwd + the sort of ``plan`` (built without run arrays for ids of this shape) + one optimizer
     schedule step (``sched``), one launch.  Returns what fm_fwd returns; ``plan`` is ready for the apply.
+    ``plan=None``: forward + schedule only (the caller sorted this batch earlier).
     ``ids_tm``: the same ids table-major, [T][B] (one array per field); read instead of ``ids`` when given."""
     _need_cuda(table.rec, toffs, ids, dense, wd, bias, labels, err, sched)
     B, T = ids.shape
-    if plan.runs or plan.n_entries != B * T or plan.bag_len != 1 or plan.T != T:
+    if plan is not None and (plan.runs or plan.n_entries != B * T or plan.bag_len != 1 or plan.T != T):
         raise MiError("fm_fwd_sort: the plan must be built with runs=False for ids of this shape")
     buf = out or {}
     f32 = dict(dtype=torch.float32, device=table.rec.device)
@@ -442,9 +443,24 @@ def fm_fwd_sort(table, toffs, ids, plan, dense=None, wd=None, bias=None, labels=
             raise MiError("fm_fwd_sort: ids_tm must be the contiguous [T][B] transpose of ids")
     src = ids if ids_tm is None else ids_tm
     _lib.call('mi_fm_fwd_sort', table.ref(), _p(toffs), T, _p(src), _idx_bits(ids), B, _p(dense), n_dense, _p(wd),
-              _p(bias), _p(labels), gscale, _p(logit), _p(S), _p(loss_rows), _p(g), _p(err), plan.total_rows,
-              _p(plan.sorted_rows), _p(plan.perm), _p(sched), lr, beta1, beta2, 0 if ids_tm is None else 1, _stream())
+              _p(bias), _p(labels), gscale, _p(logit), _p(S), _p(loss_rows), _p(g), _p(err),
+              plan.total_rows if plan is not None else 0, _p(plan.sorted_rows) if plan is not None else None,
+              _p(plan.perm) if plan is not None else None, _p(sched), lr, beta1, beta2, 0 if ids_tm is None else 1,
+              _stream())
     return dict(logit=logit, S=S, loss_rows=loss_rows, g=g)
+
+
+def fm_sort_ids(toffs, ids, plan, ids_tm=None):
+    """The per-table LDS sort of ``ids`` [B][T] (read from ``ids_tm`` [T][B] when given) into ``plan``."""
+    B, T = ids.shape
+    _need_cuda(toffs, ids, ids_tm)
+    if plan.runs or plan.n_entries != B * T or plan.bag_len != 1 or plan.T != T:
+        raise MiError("fm_sort_ids: the plan must be built with runs=False for ids of this shape")
+    if ids_tm is not None and (tuple(ids_tm.shape) != (T, B) or ids_tm.dtype != ids.dtype or not ids_tm.is_contiguous()):
+        raise MiError("fm_sort_ids: ids_tm must be the contiguous [T][B] transpose of ids")
+    src = ids.contiguous() if ids_tm is None else ids_tm
+    _lib.call('mi_fm_sort_ids', _p(toffs), T, _p(src), _idx_bits(ids), B, 0 if ids_tm is None else 1, plan.total_rows,
+              _p(plan.sorted_rows), _p(plan.perm), _stream())
 
 
 def fm_bwd_apply_dense(plan, table, g, S, opt, lr, beta1, beta2, eps, dense, loss_rows, dp, dm, dv, loss_out,

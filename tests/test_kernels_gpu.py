@@ -727,3 +727,38 @@ def test_fm_graph_survives_a_batch_of_another_shape(dev):
         assert torch.equal(la, lb)
     assert len(b._graphs) == 1
     assert torch.equal(a.table.rec, b.table.rec) and torch.equal(a.dp, b.dp)
+
+
+@pytest.mark.parametrize("opt", ["adagrad_rowwise", "adam_tf"])
+@pytest.mark.parametrize("tm", [False, True])
+def test_fm_next_batch_sort_prefetch_leaves_the_same_bits(dev, opt, tm):
+    """train_step(..., next_ids=) sorts the NEXT batch's ids on a side stream beside this step and
+    skips the sort inside the next step.  Same bits as the plain step: eager and replayed from HIP
+    graphs, with a caller that breaks its promise once (passes other ids than announced: that batch
+    is then sorted inside its own step) and with a ragged batch in between."""
+    from recommendation_amd.fm import FactorizationMachine
+    rows = [1460, 583, 30000, 305, 24, 3, 10, 4, 18, 15, 105, 27, 2173]
+    ref = ofm.State(rows, 16, 13, seed=7, opt=opt)
+    models = [FactorizationMachine(rows, 16, 13, device=dev, opt=opt, lr=1e-2) for _ in range(3)]
+    for m in models:
+        m.load_state(ref)
+    B, nb = 4096, 4
+    bat = [tuple(torch.from_numpy(x).to(dev) for x in ofm.synthetic_batch(B, rows, 13, seed=90 + j, dist='zipf'))
+           for j in range(nb)]
+    tms = [b[0].t().contiguous() if tm else None for b in bat]
+    small = tuple(torch.from_numpy(x).to(dev) for x in ofm.synthetic_batch(1000, rows, 13, seed=99, dist='zipf'))
+    order = [0, 1, 2, 3, 0, 1, 3, 2, 0, 1]            # step 6 gets batch 3 although step 5 announced batch 2
+    for k, j in enumerate(order):
+        nxt = (j + 1) % nb
+        l0 = models[0].train_step(*bat[j], ids_tm=tms[j]).clone()
+        l1 = models[1].train_step(*bat[j], ids_tm=tms[j], next_ids=bat[nxt][0], next_ids_tm=tms[nxt]).clone()
+        l2 = models[2].train_step(*bat[j], ids_tm=tms[j], next_ids=bat[nxt][0], next_ids_tm=tms[nxt], graph=True).clone()
+        assert torch.equal(l0, l1) and torch.equal(l0, l2), k
+        assert torch.equal(models[0].plan.sorted_rows, models[1].plan.sorted_rows)
+        assert torch.equal(models[0].plan.perm, models[2].plan.perm)
+        if k == 3:
+            for m in models:
+                m.train_step(*small)
+    for m in models[1:]:
+        assert torch.equal(models[0].table.rec, m.table.rec)
+        assert torch.equal(models[0].dp, m.dp) and torch.equal(models[0].sched, m.sched)
