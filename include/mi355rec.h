@@ -39,6 +39,7 @@ extern "C" {
 #define MI_IDERR_RANGE 1    /* id >= rows of its table (or negative where not allowed)    */
 #define MI_IDERR_ORDER 2    /* ids of one bag not strictly increasing (repeat / disorder) */
 #define MI_IDERR_INTERNAL 4 /* a bounded device-side wait ran out (never expected)        */
+#define MI_IDERR_CAPACITY 8 /* more rows for one rank pair than the exchange block holds  */
 
 /* flags for id validation */
 #define MI_CHECK_RANGE 1     /* id must be < rows                                         */
@@ -415,6 +416,68 @@ int mi_shard_owner_bwd_dense(const mi_fm_table* tab, int64_t local_rows, const u
 int mi_fm_dense_step_rows(const float* X, int ld, int dim, int n_dense, int64_t n, float* dp,
                           float* dm, float* dv, float lr_t, const float* lr_dev, float beta1,
                           float beta2, float eps, float* loss_out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Row-wise sharded embedding BAGS (any dim that is a multiple of 4, any bag length): the generic
+ * form of the above for models that consume the pooled rows themselves (DCN-v2, DIN, plain
+ * embedding bags).  Same placement - global row r on rank r % N as local row r / N - and the same
+ * reference counterpart (the parameter-server variable traffic, model_trainer.py:124-136).  A step:
+ *   all-gather of the ids                              [N][B][T][L]
+ *   mi_shard_bag_slots (owner view)    which bags of which rank this rank holds ids of, their rows
+ *                                      in the per-destination blocks, the owner's local ids
+ *   mi_shard_bag_gather                partial pool of every such bag -> send blocks [N][cap][dim]
+ *   all-to-all of the blocks           (fixed capacity `cap` rows per rank pair)
+ *   mi_shard_bag_slots (requester view) which owners contribute to each of MY bags, and where
+ *   mi_shard_bag_combine               pooled[b][t] = sum of the owners' rows, rank order
+ *   ... the model's interaction and loss ...
+ *   mi_shard_bag_pack                  gradient rows of my bags -> blocks in the same compact order
+ *   all-to-all of the blocks
+ *   mi_embag_bwd_prepare on the local ids + mi_embag_bwd_apply_rows: the ordinary sort-by-row
+ *                                      update of the owner's rows, gradient rows read from the blocks.
+ * With one id per bag a rank receives B*T rows per exchange in all, not N*B*T.  cap is the
+ * caller's choice (mean B*T/N rows for one-id bags; twice that covers Zipf(1.05) ids); a pair that
+ * needs more raises MI_IDERR_CAPACITY in *err and its surplus bags contribute nothing.
+ * ---------------------------------------------------------------------------------- */
+
+/* Slots.  ids: bags of bag_len ids, n_bags = B*T bags per part, bag i of a part belongs to table
+ * i % T.  owner >= 0 (owner view): ids holds n_parts parts (one per source rank, as all-gathered)
+ * and rank `owner` is asked about; owner < 0 (requester view): ids holds ONE part (this rank's ids)
+ * and part p asks which of its bags rank p contributes to (n_parts == n_ranks).  Outputs:
+ *   local_ids[n_parts][n_bags][bag_len]  (owner view; may be NULL) the owner's local id, local to its
+ *                                 share of the table (see mi_shard_bag_gather), -1 for ids it does not hold
+ *   row_of_bag[n_parts][n_bags]   p*cap + rank of the bag among part p's contributing bags, or -1
+ *   bag_of_row[n_parts*cap]       the inverse (rows beyond cnt[p] are not meaningful)
+ *   cnt[n_parts]                  rows of each block
+ * workspace: mi_shard_bag_slots_workspace_bytes(n_bags, n_parts).  Two launches. */
+size_t mi_shard_bag_slots_workspace_bytes(int64_t n_bags, int n_parts);
+int mi_shard_bag_slots(const int64_t* table_offsets, int T, const void* ids, int idx_bits, int bag_len,
+                       int64_t n_bags, int n_parts, int owner, int n_ranks, int64_t cap,
+                       int32_t* local_ids, int32_t* row_of_bag, int32_t* bag_of_row, int32_t* cnt,
+                       void* workspace, size_t workspace_bytes, int32_t* err, void* stream);
+
+/* Owner: out_rows[p*cap + slot][dim] = sum over the local ids >= 0 of bag bag_of_row[..] of part p of
+ * weights[local_table_offsets[t] + local id].  weights is this rank's share [local rows][dim];
+ * local_table_offsets[T+1] (int64, device): local rows that belong to tables before t, i.e.
+ * ceil((table_offsets[t] - rank) / N). */
+int mi_shard_bag_gather(const float* weights, const int64_t* local_table_offsets, int T, int dim,
+                        const int32_t* local_ids, int bag_len, int64_t n_bags, int n_parts, int64_t cap,
+                        const int32_t* bag_of_row, const int32_t* cnt, float* out_rows, void* stream);
+
+/* Requester: out[b][t*dim ..] = sum over parts p (ascending) with row_of_bag[p][b*T+t] >= 0 of
+ * rows[that row]; a bag no owner contributes to (all ids padding) gets zeros. */
+int mi_shard_bag_combine(const float* rows, const int32_t* row_of_bag, int n_parts, int64_t n_bags, int T,
+                         int dim, float* out, int64_t out_ld, void* stream);
+
+/* Requester, backward: rows_out[p*cap + slot] = grad[b][t*dim ..] of bag bag_of_row[p*cap + slot]. */
+int mi_shard_bag_pack(const float* grad, int64_t grad_ld, int T, int dim, const int32_t* bag_of_row,
+                      const int32_t* cnt, int n_parts, int64_t cap, float* rows_out, void* stream);
+
+/* mi_embag_bwd_apply_sgd / _adagrad_rowwise (opt = MI_OPT_SGD / MI_OPT_ADAGRAD_ROWWISE) with the bag
+ * gradients kept as compact rows: the gradient of bag i is grad_rows[row_of_bag[i]] (zero when
+ * row_of_bag[i] < 0); sum pooling only. */
+int mi_embag_bwd_apply_rows(const mi_bwd_plan* plan, const float* grad_rows, const int32_t* row_of_bag,
+                            int dim, int opt, float* weights, float* state, float lr, float eps,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bf16 MFMA contractions (DCN-v2 cross layers and MLP, DIN activation unit).  Not in the

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MI355REC_LIB') or os.path.join(_HERE, 'libmi355rec.so')
 
 MI_CHECK_RANGE, MI_CHECK_INCREASING, MI_CHECK_NONNEG = 1, 2, 4
-MI_IDERR_RANGE, MI_IDERR_ORDER, MI_IDERR_INTERNAL = 1, 2, 4
+MI_IDERR_RANGE, MI_IDERR_ORDER, MI_IDERR_INTERNAL, MI_IDERR_CAPACITY = 1, 2, 4, 8
 MI_POOL_SUM, MI_POOL_MEAN = 0, 1
 MI_DT_F32, MI_DT_BF16 = 0, 1
 MI_OPT_SGD, MI_OPT_ADAGRAD_ROWWISE, MI_OPT_ADAM_TF = 0, 1, 2
@@ -120,6 +120,13 @@ _SIGNATURES = {
     'mi_shard_bwd_scratch_floats': (c_int64, [c_int64]),
     'mi_shard_owner_bwd_dense': (c_int, [POINTER(FmTable), c_int64, P, P, P, c_int64, P, c_int, c_int, c_int64, c_int64, c_int, c_float,
                                          P, c_float, c_float, c_float, c_int, P, P, P, c_float, P, P, P, P]),
+    'mi_shard_bag_slots_workspace_bytes': (c_size_t, [c_int64, c_int]),
+    'mi_shard_bag_slots': (c_int, [P, c_int, P, c_int, c_int, c_int64, c_int, c_int, c_int, c_int64, P, P, P, P, P,
+                                   c_size_t, P, P]),
+    'mi_shard_bag_gather': (c_int, [P, P, c_int, c_int, P, c_int, c_int64, c_int, c_int64, P, P, P, P]),
+    'mi_shard_bag_combine': (c_int, [P, P, c_int, c_int64, c_int, c_int, P, c_int64, P]),
+    'mi_shard_bag_pack': (c_int, [P, c_int64, c_int, c_int, P, P, c_int, c_int64, P, P]),
+    'mi_embag_bwd_apply_rows': (c_int, [POINTER(BwdPlan), P, P, c_int, c_int, P, P, c_float, c_float, P]),
     'mi_fm_dense_step_rows': (c_int, [P, c_int, c_int, c_int, c_int64, P, P, P, c_float, P, c_float, c_float,
                                       c_float, P, P]),
 }

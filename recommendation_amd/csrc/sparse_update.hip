@@ -120,6 +120,26 @@ struct BagGradSrc {
   }
 };
 
+// gradient rows kept compactly, one per bag that has any: row_of_bag[bag] names the row (or -1: no
+// gradient for this bag).  The form in which an owner of row-wise sharded tables receives the
+// gradients of the bags it contributed to (see shard_bag.hip).
+struct RowsGradSrc {
+  static constexpr bool kBatchSingles = true;
+  const float* rows;
+  const int32_t* row_of_bag;
+  int dim;
+  template <int VEC>
+  __device__ __forceinline__ void load(const PlanDev& pl, int p, int c, float* o, float& sc) const {
+    const int r = row_of_bag[pl.bag_of(p)];
+    ldv<VEC>(rows + (int64_t) (r >= 0 ? r : 0) * dim + c * VEC, o);
+    if (r < 0) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) o[k] = 0.f;
+    }
+    sc = 0.f;
+  }
+};
+
 // FM: entry of sample b contributes g[b]*S[b] (vector) and g[b] (scalar); bag_len == 1.
 // The sample of entry p is p / T, or entry_sample[p] when given (sharded tables: the entries an
 // owner received from all ranks, each tagged with its requester's sample).
@@ -1212,6 +1232,34 @@ extern "C" int mi_embag_bwd_apply_adagrad_rowwise(const mi_bwd_plan* plan, const
   MI_REQUIRE(state, "mi_embag_bwd_apply_adagrad_rowwise: null state");
   return bag_apply<MI_OPT_ADAGRAD_ROWWISE>(plan, grad_out, grad_ld, dim, weights, state, nullptr,
                                            OptArgs{lr, 0, 0, eps, nullptr}, stream, "mi_embag_bwd_apply_adagrad_rowwise");
+}
+
+extern "C" int mi_embag_bwd_apply_rows(const mi_bwd_plan* plan, const float* grad_rows, const int32_t* row_of_bag,
+                                       int dim, int opt, float* weights, float* state, float lr, float eps,
+                                       void* stream) {
+  const char* who = "mi_embag_bwd_apply_rows";
+  PlanDev pl;
+  int rc = check_plan(plan, &pl, false, who);
+  if (rc) return rc;
+  MI_REQUIRE(grad_rows && row_of_bag && weights, "%s: null pointer", who);
+  MI_REQUIRE(plan->pool_mode == MI_POOL_SUM, "%s: sum pooling only", who);
+  MI_REQUIRE(opt == MI_OPT_SGD || (opt == MI_OPT_ADAGRAD_ROWWISE && state), "%s: optimizer must be SGD or row-wise Adagrad (with state)",
+             who);
+  Geometry g;
+  rc = geometry(dim, al16(grad_rows) && al16(weights), &g);
+  if (rc) return rc;
+  RowsGradSrc src{grad_rows, row_of_bag, dim};
+  hipStream_t s = (hipStream_t) stream;
+  if (opt == MI_OPT_SGD) {
+    BagUpd<MI_OPT_SGD> upd{weights, nullptr, nullptr, dim, OptArgs{lr, 0, 0, 0, nullptr}};
+    return run_segments(plan, pl, src, upd, g, s);
+  }
+  if (!(pow2(g.lanes) && g.lanes <= 64)) {
+    mi_set_error("%s: row-wise Adagrad needs dim/%d to be a power of two <= 64 (dim=%d)", who, g.vec, dim);
+    return MI_ERR_UNSUPPORTED;
+  }
+  BagUpd<MI_OPT_ADAGRAD_ROWWISE> upd{weights, state, nullptr, dim, OptArgs{lr, 0, 0, eps, nullptr}};
+  return run_segments(plan, pl, src, upd, g, s);
 }
 
 extern "C" int mi_embag_bwd_apply_adam_tf(const mi_bwd_plan* plan, const float* grad_out, int64_t grad_ld, int dim,

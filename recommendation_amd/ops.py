@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import (MI_CHECK_INCREASING, MI_CHECK_NONNEG, MI_CHECK_RANGE, MI_DT_BF16, MI_DT_F32,
-                   MI_IDERR_ORDER, MI_IDERR_RANGE, MI_OPT_ADAGRAD_ROWWISE, MI_OPT_ADAM_TF, MI_OPT_SGD,
+                   MI_IDERR_CAPACITY, MI_IDERR_ORDER, MI_IDERR_RANGE, MI_OPT_ADAGRAD_ROWWISE, MI_OPT_ADAM_TF, MI_OPT_SGD,
                    MI_POOL_MEAN, MI_POOL_SUM, BwdPlan, MiError)
 
 
@@ -54,7 +54,9 @@ def check_error_word(err, what="ids"):
             msgs.append("index out of bounds")
         if code & MI_IDERR_ORDER:
             msgs.append("indices of a row are out of order or repeated")
-        if code & ~(MI_IDERR_RANGE | MI_IDERR_ORDER):
+        if code & MI_IDERR_CAPACITY:
+            msgs.append("a rank pair needs more rows than the exchange block holds (raise capacity_factor)")
+        if code & ~(MI_IDERR_RANGE | MI_IDERR_ORDER | MI_IDERR_CAPACITY):
             msgs.append("internal device error 0x%x" % code)
         raise InvalidArgumentError("%s: %s" % (what, '; '.join(msgs)))
 
@@ -562,6 +564,42 @@ def shard_owner_bwd_dense(table, local_rows, sorted_rows, perm, n_total, n_slots
 def fm_dense_step_rows(X, dim, n_dense, dp, dm, dv, lr_t, beta1, beta2, eps, loss_out, lr_dev=None):
     _lib.call('mi_fm_dense_step_rows', _p(X), X.shape[1], dim, n_dense, X.shape[0], _p(dp), _p(dm), _p(dv), lr_t,
               _p(lr_dev), beta1, beta2, eps, _p(loss_out), _stream())
+
+
+# ----------------------------------------------------------------------------- sharded embedding bags
+def shard_bag_slots_workspace_bytes(n_bags, n_parts):
+    return int(_lib.load().mi_shard_bag_slots_workspace_bytes(n_bags, n_parts))
+
+
+def shard_bag_slots(toffs, T, ids, bag_len, n_bags, n_parts, owner, n_ranks, cap, local_ids, row_of_bag, bag_of_row,
+                    cnt, workspace, err=None):
+    """Which bags rank ``owner`` contributes to (owner view, ``ids`` = all ranks' ids) or, with
+    owner=-1, which owners contribute to this rank's bags (requester view); see mi_shard_bag_slots."""
+    _need_cuda(toffs, ids, local_ids, row_of_bag, bag_of_row, cnt, workspace, err)
+    _lib.call('mi_shard_bag_slots', _p(toffs), T, _p(ids), _idx_bits(ids), bag_len, n_bags, n_parts, owner, n_ranks, cap,
+              _p(local_ids), _p(row_of_bag), _p(bag_of_row), _p(cnt), _p(workspace), workspace.numel(), _p(err),
+              _stream())
+
+
+def shard_bag_gather(weights, ltoffs, T, local_ids, bag_len, n_bags, n_parts, cap, bag_of_row, cnt, out_rows):
+    _lib.call('mi_shard_bag_gather', _p(weights), _p(ltoffs), T, weights.shape[1], _p(local_ids), bag_len, n_bags,
+              n_parts, cap, _p(bag_of_row), _p(cnt), _p(out_rows), _stream())
+
+
+def shard_bag_combine(rows, row_of_bag, n_parts, n_bags, T, dim, out):
+    _lib.call('mi_shard_bag_combine', _p(rows), _p(row_of_bag), n_parts, n_bags, T, dim, _p(out), out.stride(0),
+              _stream())
+
+
+def shard_bag_pack(grad, T, dim, bag_of_row, cnt, n_parts, cap, rows_out):
+    _lib.call('mi_shard_bag_pack', _p(grad), grad.stride(0), T, dim, _p(bag_of_row), _p(cnt), n_parts, cap,
+              _p(rows_out), _stream())
+
+
+def bwd_apply_rows(plan, grad_rows, row_of_bag, weights, opt, lr, state=None, eps=1e-8):
+    """Sparse update with the bag gradients given as compact rows (grad_rows[row_of_bag[bag]])."""
+    _lib.call('mi_embag_bwd_apply_rows', plan.ref(), _p(grad_rows), _p(row_of_bag), weights.shape[1], opt, _p(weights),
+              _p(state), lr, eps, _stream())
 
 
 # ----------------------------------------------------------------------------- bf16 MFMA contractions
