@@ -62,8 +62,9 @@ def parse_args():
                     help='use the row-wise sharded model and its collectives even with one rank (rehearsal of the N > 1 path)')
     ap.add_argument('--bag-len', type=int, default=1, help='embag workload: ids per bag (sum pooling)')
     ap.add_argument('--embag-rows', type=int, default=1000000000 // 8,
-                    help='embag workload: total rows over the 26 tables (default: one GPU\'s eighth of 1 G rows)')
-    ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer', 'embag'],
+                    help='embag workload: total rows over the 26 tables (default: one GPU\'s eighth of 1 G rows); '
+                         'sharded_embag: rows PER RANK')
+    ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer', 'embag', 'sharded_embag'],
                     help='fm (default, the headline configuration); dcn / din: the bf16 matrix-core configurations, 1 GPU')
     args = ap.parse_args()
     if args.opt is None:
@@ -499,6 +500,165 @@ def bench_embag(args):
     return res
 
 
+def bench_sharded_embag(args):
+    """Row-wise sharded embedding bags, the 1 G-row x dim-128 configuration: every rank holds
+    --embag-rows rows (default 125 M = 64 GB fp32: an eighth of 1 G rows, so 8 ranks hold the whole
+    configuration) of 8 tables dealt round robin over the ranks, batch 8192 per rank (65536 at 8
+    ranks), one id per bag, row-wise Adagrad.  A step = all-gather of ids, owner partial pools,
+    all-to-all of pooled rows, combine; a fixed synthetic upstream gradient; all-to-all of gradient
+    rows, sort by row, fused update.  Weak scaling: rows and batch per rank are fixed."""
+    from recommendation_amd import ops
+    from recommendation_amd.sharded_bag import ShardedEmbeddingBag
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)          # RCCL prints a banner on stdout; the JSON line must be alone there
+    os.dup2(2, 1)
+    if world == 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29578')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    torch.distributed.init_process_group('nccl', device_id=dev)
+    T, L = 8, args.bag_len
+    D = args.dim if args.dim != 16 else 128
+    B = args.batch
+    opt = args.opt if args.opt in ('sgd', 'adagrad_rowwise') else 'adagrad_rowwise'
+    rows = [args.embag_rows * world // T] * T
+    m = ShardedEmbeddingBag(rows, D, L, dev, opt=opt, lr=0.01, seed=0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 + rank)
+    card = torch.tensor(rows, dtype=torch.float64, device=dev).view(1, T, 1)
+    idt = torch.int64 if args.idx_bits == 64 else torch.int32
+    batches = []
+    for _ in range(8):
+        u = torch.rand((B, T, L), generator=g, dtype=torch.float64, device=dev)
+        if args.dist == 'zipf':
+            a = 1.0 - 1.05
+            ids = torch.floor(((u * ((card + 1.0) ** a - 1.0)) + 1.0) ** (1.0 / a)) - 1.0
+        else:
+            ids = torch.floor(u * card)
+        batches.append(torch.minimum(ids.clamp_(min=0), card - 1).to(idt).contiguous())
+    grad = torch.randn((B, T * D), generator=g, dtype=torch.float32, device=dev).mul_(1e-3)
+    it = [0]
+
+    def step():
+        m.forward(batches[it[0] % len(batches)])
+        m.backward(grad)
+        it[0] += 1
+
+    def barrier():
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    m.be.check()
+    res = None
+    if rank == 0:
+        ib = args.idx_bits // 8
+        n_bags = B * T
+        res = {'metric': 'train_samples_per_sec', 'value': round(B * world * args.steps / dt, 1), 'unit': 'samples/s',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'sharded_embag_%dx%d_rows%dM_per_rank_b%d_l%d' % (T, D, args.embag_rows // 1000000, B, L),
+                          'global_batch': B * world, 'tables': T, 'total_rows': int(sum(rows)), 'rows_per_rank': m.be.local_rows,
+                          'dim': D, 'bag_len': L, 'pooling': 'sum', 'id_bits': args.idx_bits, 'ids': args.dist,
+                          'optimizer': '%s (fused into the sparse backward)' % opt, 'launch': 'eager',
+                          'placement': 'global row r on rank r %% %d as local row r / %d' % (world, world),
+                          'capacity_rows_per_rank_pair': m.cap,
+                          'parallelism': 'rowwise-sharded tables x%d, pooled rows exchanged' % world}}
+        res['collectives'] = {'all_gather_ids_bytes_received': world * n_bags * L * ib,
+                              'all_to_all_pooled_rows_bytes_per_rank': world * m.cap * D * 4,
+                              'all_to_all_gradient_rows_bytes_per_rank': world * m.cap * D * 4,
+                              'rows_that_carry_data_per_exchange': n_bags if L == 1 else None}
+    # per-launch stages on rank 0's buffers of the last step (no collectives inside)
+    ids = batches[(it[0] - 1) % len(batches)]
+    n_own = int(m.own_cnt.sum().item())
+    n_ent = int((m.local_ids >= 0).sum().item())
+    plan = m.be._plan
+    U = int(torch.unique(plan.sorted_rows[:plan.n_entries]).numel()) - (1 if n_ent < plan.n_entries else 0)
+    stages = []
+    for name, fn, nb in (
+            ('owner slots (2 launches: ownership flags, local ids, block rows)',
+             lambda: m.be.owner_slots(m.ids_all, m.n_bags, m.cap, m.local_ids, m.own_row_of_bag, m.own_bag_of_row, m.own_cnt, m.ws),
+             world * n_bags * L * (ib + 4) + world * n_bags * 5),
+            ('owner gather + partial pooling', lambda: m.be.gather(m.local_ids, m.n_bags, m.cap, m.own_bag_of_row, m.own_cnt, m.rows_out),
+             n_own * (4 + L * 4) + n_ent * D * 4 + n_own * D * 4),
+            ('requester slots (2 launches)',
+             lambda: m.be.requester_slots(ids, m.n_bags, m.cap, m.req_row_of_bag, m.req_bag_of_row, m.req_cnt, m.ws),
+             n_bags * L * ib + world * n_bags * 5),
+            ('requester combine', lambda: m.be.combine(m.rows_in, m.req_row_of_bag, m.n_bags, m.pooled),
+             world * n_bags * 4 + n_bags * D * 4 * 2),
+            ('requester gradient pack', lambda: m.be.pack(grad, m.req_bag_of_row, m.req_cnt, m.cap, m.grad_out),
+             n_bags * (4 + D * 4 * 2)),
+            ('owner sort by row', lambda: plan.prepare(m.local_ids), plan.n_entries * 12),
+            ('owner sparse backward + fused %s' % opt,
+             lambda: ops.bwd_apply_rows(plan, m.grad_in, m.own_row_of_bag, m.be.W, ops.MI_OPT_SGD if opt == 'sgd' else ops.MI_OPT_ADAGRAD_ROWWISE, 0.0, state=m.be.state),
+             n_ent * (8 + 4 + D * 4) + U * (D + (1 if opt != 'sgd' else 0)) * 4 * 2)):
+        ms = time_stage(fn, args.stage_reps)
+        stages.append(dict(name=name, ms=round(ms, 5), alg_bytes=int(nb), gbs=round(nb / ms / 1e6, 1)))
+    if rank == 0:
+        res['stages'] = stages
+        res['entries_at_this_owner'] = n_ent
+        res['unique_rows_per_step'] = U
+        hbm = [stages[1], stages[6]]
+        dom = max(hbm, key=lambda s: s['ms'])
+        res['embedding_hbm_gbs'] = round(sum(s['alg_bytes'] for s in hbm) / sum(s['ms'] for s in hbm) / 1e6, 1)
+        res['roofline'] = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': round(dom['gbs'] / HBM_PEAK_GBS, 4), 'traffic': None, 'traffic_source': None,
+                           'alg_bytes_per_launch': dom['alg_bytes'], 'ms_per_launch': dom['ms']}
+        if not args.no_cpu_baseline:
+            from oracle import embedding as oe
+            rc = 100000
+            rng = np.random.default_rng(0)
+            toffs_c = np.arange(T + 1, dtype=np.int64) * rc
+            Wc = (rng.standard_normal((T * rc, D)) * 0.05).astype(np.float32)
+            stc = np.zeros(T * rc, np.float32)
+            idc = rng.integers(0, rc, size=(B, T, L)).astype(np.int64)
+            gc = grad.cpu().numpy()
+
+            def cpu_step():
+                oe.embag_fwd(Wc, toffs_c, T, idc, bag_len=L)
+                grads = oe.row_grads(toffs_c, T, idc, gc, D, bag_len=L)
+                if opt == 'sgd':
+                    oe.apply_sgd(Wc, grads, 0.01)
+                else:
+                    oe.apply_adagrad_rowwise(Wc, stc, grads, 0.01, 1e-8)
+
+            cpu_step()
+            times = []
+            t_end = time.perf_counter() + 20.0
+            while len(times) < args.cpu_steps and time.perf_counter() < t_end:
+                c0 = time.perf_counter()
+                cpu_step()
+                times.append(time.perf_counter() - c0)
+            res['cpu_baseline'] = dict(value=round(B / float(np.median(times)), 1), unit='samples/s', cores=1, kind='port',
+                                       sample='median of %d steps of the same batch (%d x %d bags, dim %d) on ONE rank\'s work, tables cut '
+                                              'to %d rows each, through the numpy oracle (per-bag loops, one thread)'
+                                              % (len(times), B, T, D, rc))
+    torch.distributed.barrier()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    os.dup2(2, 1)
+    torch.distributed.destroy_process_group()
+
+
 def bench_din(args):
     """DIN local activation unit (1 M items x dim 64, history 100, lengths U[1,100], MLP 256-80-40-1), batch 8192."""
     from recommendation_amd import ops
@@ -642,6 +802,13 @@ def main():
     if args.workload == 'infer':
         torch.cuda.set_device(0)
         print(json.dumps(bench_infer(args)))
+        return
+    if args.workload == 'sharded_embag':
+        if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+            raise SystemExit(spawn_ranks(args.gpus))
+        if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
+            raise SystemExit("WORLD_SIZE=%s does not match --gpus %d" % (os.environ.get('WORLD_SIZE'), args.gpus))
+        bench_sharded_embag(args)
         return
     if args.workload != 'fm':
         if args.gpus != 1 or int(os.environ.get('WORLD_SIZE', '1')) != 1:

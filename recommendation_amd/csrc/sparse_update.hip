@@ -748,8 +748,11 @@ static_assert(FM_DENSE_THREADS == UBLOCK, "the dense side runs in workgroups of 
 // three), 0 for any other width (lanes is then read from the argument).
 template <int VEC, bool SPLIT, int LP, class Src, class Upd, class Extra>
 __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src, Upd upd, int lanes_arg, int groups,
-                                                           int long_blocks, Extra extra) {
+                                                           int long_blocks, Extra extra, int epw_arg) {
   const int lanes = LP > 0 ? LP : lanes_arg;
+  // entries per wave: 64, or fewer (wide rows, few entries) so that a small batch still spreads over
+  // the chip - a wave of 64 entries with two lane groups is 8 or more rounds of dependent loads
+  const int epw = LP > 0 ? 64 : epw_arg;
   if (pl.n_dev) pl.n = min(pl.n, pl.n_dev[0]);
   const uint32_t* keys = pl.sorted_rows;
   const uint32_t sentinel = pl.sentinel;
@@ -922,24 +925,26 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
     return;
   }
   const int lane = threadIdx.x & 63;
-  const int base = ((bid - long_blocks) * (UBLOCK / 64) + (threadIdx.x >> 6)) * 64;
+  const int base = ((bid - long_blocks) * (UBLOCK / 64) + (threadIdx.x >> 6)) * epw;
   if (base >= pl.n) return;  // uniform over the wave
   const int i = base + lane;
-  const uint32_t key = i < pl.n ? keys[i] : sentinel;
-  // the wave's 64 permutation entries, requested with its rows (one coalesced load): a run that closes
+  const bool mine = lane < epw && i < pl.n;
+  const uint32_t key = mine ? keys[i] : sentinel;
+  // the wave's permutation entries, requested with its rows (one coalesced load): a run that closes
   // inside the wave gets its entries by shuffle instead of a dependent load per run
-  const int perm_reg = pl.perm[i < pl.n ? i : base];
-  uint32_t edge = sentinel;  // lane 0: the row before the wave's first; lane 63: the row after its last
+  const int perm_reg = pl.perm[mine ? i : base];
+  uint32_t edge = sentinel;  // lane 0: the row before the wave's first; lane epw-1: the row after its last
   if (lane == 0 && base > 0) edge = keys[base - 1];
-  if (lane == 63 && base + 64 < pl.n) edge = keys[base + 64];
+  if (lane == epw - 1 && base + epw < pl.n) edge = keys[base + epw];
   uint32_t prev = (uint32_t) __shfl_up((int) key, 1, 64);
   const uint32_t before = (uint32_t) __shfl((int) edge, 0, 64);
-  const uint32_t after_wave = (uint32_t) __shfl((int) edge, 63, 64);
+  const uint32_t after_wave = (uint32_t) __shfl((int) edge, epw - 1, 64);
   if (lane == 0) prev = base > 0 ? before : ~key;
   // Every change of row starts a run, padding (sentinel) runs included - those are skipped below.
   // (After a per-table sort the sentinels close each table's block instead of the whole array.)
+  const unsigned long long wmask = epw >= 64 ? ~0ull : ((1ull << epw) - 1ull);  // the lanes that hold entries
   const bool head = key != prev;
-  const unsigned long long hm = __ballot(head);
+  const unsigned long long hm = __ballot(head) & wmask;
   const int nheads = __popcll(hm);
   if constexpr (LP > 0) {
     __shared__ float lds_cs[UBLOCK / 64][64 * (LP * VEC + 4)];
@@ -957,14 +962,14 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
     // and row states requested together, then the four gradient rows - instead of one run per round.
     // Nothing in the round is conditional (a branch around a load makes the compiler wait for all
     // outstanding loads where the paths join, which would serialise the four again).
-    const uint32_t last_key = (uint32_t) __shfl((int) key, 63, 64);
+    const uint32_t last_key = (uint32_t) __shfl((int) key, epw - 1, 64);
     constexpr int BT = Upd::kBatchSingles;  // rows per lane group per round
     // (a per-table sort leaves padding entries at the end of each TABLE's block, so a lone one can sit
     // anywhere in the wave and still differ from both neighbours: every lane is checked, not the last)
-    const bool no_padding = __ballot(key == sentinel) == 0ull;
-    if (hm == ~0ull && lanes >= BT && base + 64 <= pl.n && no_padding &&
-        !(base + 64 < pl.n && after_wave == last_key)) {  // uniform
-      for (int r0 = 0; r0 < lanes; r0 += BT) {  // 64 / G = lanes rounds, a power of two >= BT
+    const bool no_padding = (__ballot(key == sentinel) & wmask) == 0ull;
+    if (hm == wmask && lanes >= BT && epw >= BT * G && base + epw <= pl.n && no_padding &&
+        !(base + epw < pl.n && after_wave == last_key)) {  // uniform
+      for (int r0 = 0; r0 * G < epw; r0 += BT) {  // epw / G rounds of one row per group, BT of them at a time
         uint32_t row[BT];
         int p[BT];
         typename Upd::template Regs<VEC> regs[BT];
@@ -993,14 +998,14 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
     const int k = r * G + g;
     const int pos = k < nheads ? kth_set_bit(hm, k) : 0;
     const unsigned long long later = (pos < 63) ? (hm & ~((2ull << pos) - 1ull)) : 0ull;  // heads after pos
-    const int endpos = later ? __ffsll((long long) later) - 1 : 64;
+    const int endpos = later ? __ffsll((long long) later) - 1 : epw;
     const uint32_t row = (uint32_t) __shfl((int) key, pos, 64);
     const bool have = k < nheads && row != sentinel;
-    const bool open = have && !later && base + 64 < pl.n && after_wave == row;  // continues in the next wave
+    const bool open = have && !later && base + epw < pl.n && after_wave == row;  // continues in the next wave
     const int len = endpos - pos;
     int p4[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) p4[q] = __shfl(perm_reg, pos + q < 64 ? pos + q : pos, 64);  // every lane takes part
+    for (int q = 0; q < 4; ++q) p4[q] = __shfl(perm_reg, pos + q < epw ? pos + q : pos, 64);  // every lane takes part
     bool pending = false;
     if (have) {
       if (!open && len <= 4) group_run4_pre<VEC>(pl, src, upd, lanes, c, p4, len, row);
@@ -1146,10 +1151,18 @@ int run_segments(const mi_bwd_plan* plan, const PlanDev& pl, const Src& src, con
     pls.split = (int64_t) long_blocks * (1 + 2 * (g.lanes * g.vec + 1)) <= plan->n_entries &&
                         plan->n_entries < ((int64_t) 1 << 30) && per_table > MI_SPLIT_GATE * SPLIT_MIN
                     ? 1 : 0;
-    const unsigned grid = (unsigned) (extra.blocks + long_blocks + mi_cdiv(plan->n_entries, UBLOCK));
+    // entries per wave: 64, halved (down to 16, and never below four rows per lane group) while that leaves
+    // fewer than 8192 waves - rows of 32 lanes give a wave of 64 entries 8 to 32 dependent rounds, and a
+    // batch of 65536 such entries would occupy one wave per SIMD
+    int epw = 64;
+    if (g.lanes > 4) {
+      const int floor_epw = 4 * (64 / g.lanes) > 16 ? 4 * (64 / g.lanes) : 16;
+      while (epw > floor_epw && plan->n_entries / epw < 8192) epw >>= 1;
+    }
+    const unsigned grid = (unsigned) (extra.blocks + long_blocks + mi_cdiv(plan->n_entries, (int64_t) epw * (UBLOCK / 64)));
 #define SEG_LAUNCH(V, SP, LP)                                                                                          \
   hipLaunchKernelGGL((seg_sorted_kernel<V, SP, LP, Src, Upd, Extra>), dim3(grid), dim3(UBLOCK), 0, s, pls, src, upd,   \
-                     g.lanes, g.gpb, long_blocks, extra)
+                     g.lanes, g.gpb, long_blocks, extra, epw)
 #define SEG_LANES(V, SP)                                                                                               \
   switch (g.lanes) {                                                                                                   \
     case 1: SEG_LAUNCH(V, SP, 1); break;                                                                               \

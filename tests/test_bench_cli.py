@@ -105,3 +105,11 @@ def test_embag_line_small_tables(dev, opt):
                             '1', '--stage-reps', '2', '--no-cpu-baseline'))
     assert d['config']['dim'] == 128 and d['config']['optimizer'].startswith(opt)
     assert d['embedding_hbm_gbs'] > 0 and len(d['stages']) == 3
+
+
+@pytest.mark.gpu
+def test_sharded_embag_line_one_rank_over_rccl(dev):
+    d = _one_json_line(_run('--workload', 'sharded_embag', '--embag-rows', '800000', '--batch', '1024', '--steps', '3',
+                            '--warmup', '1', '--stage-reps', '2', '--cpu-steps', '1'))
+    assert d['config']['dim'] == 128 and d['n_gpus'] == 1 and d['config']['global_batch'] == 1024
+    assert len(d['stages']) == 7 and d['cpu_baseline']['value'] > 0
