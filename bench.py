@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument('--embag-rows', type=int, default=1000000000 // 8,
                     help='embag workload: total rows over the 26 tables (default: one GPU\'s eighth of 1 G rows); '
                          'sharded_embag: rows PER RANK')
-    ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer', 'embag', 'sharded_embag'],
+    ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer', 'embag', 'sharded_embag', 'colour'],
                     help='fm (default, the headline configuration); dcn / din: the bf16 matrix-core configurations, 1 GPU')
     args = ap.parse_args()
     if args.opt is None:
@@ -725,6 +725,62 @@ def bench_din(args):
     return res
 
 
+def bench_colour(args):
+    """The reference's own model and train step (recommendation/local_train_utils.py:30-66:
+    RecommendationModel(128, 6, 100, 20), batch 300, tf.train.AdamOptimizer(1e-4)) on the GPU, beside the
+    numpy oracle's restatement of the reference's formulation on the host: dense one-hot / n-hot
+    matrices materialised and multiplied into the first kernels, dense TensorFlow-form Adam."""
+    from oracle import colour_model as cm
+    from recommendation_amd.r_model import RecommendationModel
+    from recommendation_amd.trainer import AdamOptimizer, train_step
+    dev = torch.device('cuda', 0)
+    B = args.batch if args.batch != 8192 else 300
+    params = cm.init_params(seed=1, dtype=np.float32)
+    m = RecommendationModel(128, 6, 100, 20, device=dev)
+    m.load_variables(params)
+    m.check_every = 64                 # the id error word is read every 64 steps and once at the end
+    opt = AdamOptimizer(learning_rate=1e-4)
+    host = [cm.synthetic_batch(B, seed=20211207 + j) for j in range(8)]
+    batches = [tuple(torch.from_numpy(b[k]).to(dev) for k in cm._KEYS) for b in host]
+    it = [0]
+
+    def step():
+        train_step(m, opt, batches[it[0] % len(batches)])
+        it[0] += 1
+
+    dt = _timed_steps(step, args)
+    m.check_errors()
+    res = _line(args, 'colour_model_train_b%d' % B, B, dt, 'f32',
+                dict(model='RecommendationModel(128, 6, 100, 20)', parameters=5910, optimizer='adam_tf (dense, lr 1e-4)',
+                     includes='encoders, 11 linear layers, softmax / top-6 / accuracy / loss, backward, Adam'))
+    # plumbing, not a bandwidth workload: a sample is 16 ids and 16 gathered rows (124 floats); the step is
+    # bound by the launches of a 5,910-parameter model
+    nbytes = B * (16 * 4 + 124 * 4 + 2 * 128 * 4) + 3 * 2 * 5910 * 4
+    ms = dt / args.steps * 1e3
+    res['roofline'] = {'kernel': 'whole step (about 40 launches of a 5,910-parameter model: launch-bound)', 'bound': 'hbm',
+                       'achieved': round(nbytes / ms / 1e6, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                       'frac': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 6), 'traffic': None, 'traffic_source': None,
+                       'alg_bytes_per_launch': nbytes, 'ms_per_launch': round(ms, 5)}
+    if not args.no_cpu_baseline:
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        p32 = {n: p.copy() for n, p in params.items()}
+        copt = cm.AdamTF(p32, lr=1e-4)
+        for k in range(10):
+            cm.train_step(p32, copt, host[k % len(host)])
+        times = []
+        t_end = time.perf_counter() + 30.0
+        while len(times) < args.cpu_steps and time.perf_counter() < t_end:
+            c0 = time.perf_counter()
+            cm.train_step(p32, copt, host[len(times) % len(host)])
+            times.append(time.perf_counter() - c0)
+        res['cpu_baseline'] = dict(value=round(B / float(np.median(times)), 1), unit='samples/s', cores=cores, kind='port',
+                                   sample='median of %d steps after 10 warm-up steps, same batches of %d, through the numpy '
+                                          'oracle in the reference\'s formulation (one-hot / n-hot matrices materialised, '
+                                          'matmul, dense Adam; fp32; numpy\'s BLAS on %d threads)' % (len(times), B, cores))
+    return res
+
+
 def bench_infer(args):
     """ModelInference.inference on record strings (tokenizer + colour-model forward + top-6 + string
     formatting): the serving-side consumer of the forward path, batch 4096 unless --batch is given."""
@@ -814,7 +870,7 @@ def main():
         if args.gpus != 1 or int(os.environ.get('WORLD_SIZE', '1')) != 1:
             raise SystemExit("--workload %s is a single-GPU configuration" % args.workload)
         torch.cuda.set_device(0)
-        fn = {'dcn': bench_dcn, 'din': bench_din, 'embag': bench_embag}[args.workload]
+        fn = {'dcn': bench_dcn, 'din': bench_din, 'embag': bench_embag, 'colour': bench_colour}[args.workload]
         print(json.dumps(fn(args)))
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:

@@ -132,6 +132,8 @@ class RecommendationModel(object):
         self.country_count = country_count
         self.device = torch.device(device if device is not None else 'cuda:0')
         self.validate = validate
+        self.check_every = 1
+        self._feature_calls = 0
         self._gen = torch.Generator(device='cpu')
         self._gen.manual_seed(0 if seed is None else int(seed))
         self._arena = torch.zeros(0, dtype=torch.float32, device=self.device)
@@ -254,7 +256,13 @@ class RecommendationModel(object):
         c_c_1 = self.input_to_one_hot_plus(features['click_colour_1'], self.colour_count)
         r_c_2 = self.input_to_n_hot(features['recommend_colours_2'], self.colour_count)
         c_c_2 = self.input_to_one_hot_plus(features['click_colour_2'], self.colour_count)
-        self.check_errors()
+        # The error word is read (a host-device synchronisation) every `check_every` calls: 1 reports a
+        # bad id in the call that fed it, as session.run does; a training loop that can live with hearing
+        # of it a few steps later (the bad ids are never dereferenced meanwhile) sets it higher and calls
+        # check_errors() once at the end.
+        self._feature_calls += 1
+        if self.check_every and self._feature_calls % self.check_every == 0:
+            self.check_errors()
         return {'user': user_fs, 'country': country_fs, 'recommend_colours_1': r_c_1, 'click_colour_1': c_c_1,
                 'recommend_colours_2': r_c_2, 'click_colour_2': c_c_2}
 

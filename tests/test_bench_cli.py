@@ -113,3 +113,9 @@ def test_sharded_embag_line_one_rank_over_rccl(dev):
                             '--warmup', '1', '--stage-reps', '2', '--cpu-steps', '1'))
     assert d['config']['dim'] == 128 and d['n_gpus'] == 1 and d['config']['global_batch'] == 1024
     assert len(d['stages']) == 7 and d['cpu_baseline']['value'] > 0
+
+
+@pytest.mark.gpu
+def test_colour_line(dev):
+    d = _one_json_line(_run('--workload', 'colour', '--steps', '5', '--warmup', '2', '--cpu-steps', '3'))
+    assert d['config']['workload'] == 'colour_model_train_b300' and d['cpu_baseline']['kind'] == 'port'
