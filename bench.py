@@ -64,6 +64,7 @@ def parse_args():
     ap.add_argument('--embag-rows', type=int, default=1000000000 // 8,
                     help='embag workload: total rows over the 26 tables (default: one GPU\'s eighth of 1 G rows); '
                          'sharded_embag: rows PER RANK')
+    ap.add_argument('--din-items', type=int, default=8000000, help='din workload: rows of the item table')
     ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer', 'embag', 'sharded_embag', 'colour'],
                     help='fm (default, the headline configuration); dcn / din: the bf16 matrix-core configurations, 1 GPU')
     args = ap.parse_args()
@@ -347,17 +348,29 @@ def bench_dcn(args):
                 dict(tables=len(rows), total_rows=int(sum(rows)), dim=16, n_dense=13, d_padded=m.dp, cross_layers=3,
                      mlp=[1024, 1024, 512, 1], accumulate='f32', optimizer='adam_tf (dense) + adagrad_rowwise (tables)'))
     res['step_tflops'] = round(m.flops_per_sample() * B * args.steps / dt / 1e12, 1)
-    # dominant kernel: the contraction.  Timed on the largest one of the step (the 1024x1024 MLP layer).
-    X, W, out = m.h[0], m.Wm[1].h, m.h[1]
-    ms = time_stage(lambda: ops.gemm_bf16(X, W, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=out, bias=m.bm[1].w),
-                    args.stage_reps)
-    flops = 2.0 * B * W.shape[0] * W.shape[1]
-    res['roofline'] = {'kernel': 'gemm_bf16_kernel (MLP layer %dx%d forward, M=%d)' % (W.shape[0], W.shape[1], B),
+    # every contraction launch of the step timed on its own, by kernel class: 'row' = gemm_bf16_kernel with both
+    # operands stored reduction-contiguous (forward layers and data gradients), 'wgrad' = both reduction-major
+    # (weight gradients).  The roofline line is the class that takes more of the step, ALL its launches summed.
+    per = []
+    for cls, name, fn, flops in m.contraction_calls():
+        ms = time_stage(fn, max(2, args.stage_reps // 5))
+        per.append(dict(kernel_class=cls, name=name, ms=round(ms, 5), flops=flops, tflops=round(flops / ms / 1e9, 1)))
+    res['contractions'] = per
+    tot = {c: (sum(p['flops'] for p in per if p['kernel_class'] == c), sum(p['ms'] for p in per if p['kernel_class'] == c))
+           for c in ('row', 'wgrad')}
+    res['contraction_classes'] = {c: dict(launches=sum(1 for p in per if p['kernel_class'] == c), ms=round(t, 4),
+                                          tflops=round(f / t / 1e9, 1)) for c, (f, t) in tot.items()}
+    dom = max(tot, key=lambda c: tot[c][1])
+    flops, ms = tot[dom]
+    n_launch = res['contraction_classes'][dom]['launches']
+    res['roofline'] = {'kernel': 'gemm_bf16_kernel, %s operands: the %d launches of one step (%s)' % (
+                           'row-stored' if dom == 'row' else 'reduction-major', n_launch,
+                           'forward layers + data gradients' if dom == 'row' else 'weight gradients'),
                        'bound': 'mfma', 'achieved': round(flops / ms / 1e9, 1), 'peak': MFMA_PEAK_TFLOPS,
                        'unit': 'TFLOP/s', 'frac': round(flops / ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
-                       'traffic': _pmc_traffic('r01_dcn_b65536_pmc.json', res['config']['workload'],
-                                               'gemm_bf16_kernel fwd 1024x1024 M=65536'),
-                       'alg_flops_per_launch': flops, 'ms_per_launch': round(ms, 5)}
+                       'traffic': None, 'traffic_source': None,
+                       'alg_flops_per_launch': flops / n_launch, 'ms_per_launch': round(ms / n_launch, 5),
+                       'share_of_step': round(ms / (dt / args.steps * 1e3), 3)}
     if not args.no_cpu_baseline:
         from oracle import dcn as odcn
         Bc = 4096
@@ -660,11 +673,12 @@ def bench_sharded_embag(args):
 
 
 def bench_din(args):
-    """DIN local activation unit (1 M items x dim 64, history 100, lengths U[1,100], MLP 256-80-40-1), batch 8192."""
+    """DIN local activation unit (8 M items x dim 64 = 2 GB, far past the 256 MiB last-level cache, so that the
+    gather's rate is an HBM rate; history 100, lengths U[1,100], MLP 256-80-40-1), batch 8192."""
     from recommendation_amd import ops
     from recommendation_amd.din import DIN
     dev = torch.device('cuda', 0)
-    B, L, rows = args.batch, 100, 1000000
+    B, L, rows = args.batch, 100, args.din_items
     m = DIN(rows, dev, max_len=L, factored=False if args.din_full_rows else None)
     g = torch.Generator(device=dev)
     g.manual_seed(1000)
@@ -685,16 +699,15 @@ def bench_din(args):
 
     dt = _timed_steps(step, args)
     ops.check_error_word(m.err, "bench ids")
-    res = _line(args, 'din_lau_1Mx64_L%d_b%d' % (L, B), B, dt, 'bf16',
+    res = _line(args, 'din_lau_%dMx64_L%d_b%d' % (rows // 1000000, L, B), B, dt, 'bf16',
                 dict(items=rows, dim=64, history=L, lengths='U[1,%d]' % L, lau_mlp=[256, 80, 40, 1],
                      hidden_padded=[m.h1p, m.h2p], accumulate='f32',
                      optimizer='adam_tf (dense) + adagrad_rowwise (table)'))
     res['step_tflops'] = round(m.flops_per_sample() * B * args.steps / dt / 1e12, 1)
     # dominant HBM kernel: the gather that builds the unit's input rows
-    hist, qid, lens, labels = batches[0]
-    ms = time_stage(lambda: ops.din_lau_build(m.E, hist, qid, lens, m.A, m.ids_all, q_out=m.feat[:, 64:], err=m.err),
-                    args.stage_reps)
-    live = int(lens.sum().item())
+    ms = time_rotating(lambda j: ops.din_lau_build(m.E, batches[j][0], batches[j][1], batches[j][2], m.A, m.ids_all,
+                                                   q_out=m.feat[:, 64:], err=m.err), len(batches), args.stage_reps)
+    live = sum(int(b[2].sum().item()) for b in batches) / float(len(batches))
     ib = args.idx_bits // 8
     nbytes = live * 64 * 4 + B * L * ib + B * L * m.A.shape[1] * 2 + B * (L + 1) * 4   # live rows + ids + A rows + index list
     res['config']['first_layer'] = 'factored: rows [k | q*k], q term per sample' if m.factored else 'full rows [q | k | q-k | q*k]'
@@ -702,8 +715,9 @@ def bench_din(args):
                        'bound': 'hbm',
                        'achieved': round(nbytes / ms / 1e6, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
-                       'traffic': _pmc_traffic('r01_din_b8192_pmc.json', res['config']['workload'],
+                       'traffic': _pmc_traffic('r02_din_b8192_pmc.json', res['config']['workload'],
                                                'din_build_kernel factored' if m.factored else 'din_build_kernel'),
+                       'traffic_source': 'quoted profiles/r02_din_b8192_pmc.json (null when absent or another workload)',
                        'alg_bytes_per_launch': nbytes, 'ms_per_launch': round(ms, 5)}
     if not args.no_cpu_baseline:
         from oracle import din as odin
