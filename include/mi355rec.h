@@ -278,7 +278,9 @@ int mi_fm_fwd(const mi_fm_table* tab, const int64_t* table_offsets, int T, const
 /* FM backward fused with the sparse update of V and w1.  For distinct row r with run
  * {b_i}: dV[r] = sum_i g[b_i]*S[b_i] - V[r]*sum_i g[b_i];  dw1[r] = sum_i g[b_i].
  * plan comes from mi_embag_bwd_prepare on ids (bag_len 1); its run arrays may be NULL.
- * The sample of entry p is p / T, or entry_sample[p] when entry_sample != NULL (sharded tables).
+ * The sample of entry p is p / T; entry_sample must be NULL (kept for ABI stability: a caller with
+ * another entry -> sample map sorts with T = 1 and the sample index as the sort's payload, as
+ * mi_shard_owner_bwd_dense does).
  * lr is alpha_t for MI_OPT_ADAM_TF (see mi_adam_tf_dense); when lr_dev != NULL the step
  * size is read from lr_dev[0] on the device instead (see mi_adam_schedule_step), which lets a
  * captured HIP graph be replayed step after step. */

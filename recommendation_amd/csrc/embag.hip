@@ -91,8 +91,9 @@ __global__ __launch_bounds__(EMBAG_BLOCK) void embag_fwd_kernel(
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t j = j0 + u;
-      id[u] = (j < end) ? mi_ld_id<IDX>(indices, j) : (int64_t) -1;
       const bool present = (j < end);
+      id[u] = mi_ld_id<IDX>(indices, present ? j : j0);
+      if (!present) id[u] = -1;
       if (present) {
         if (id[u] < 0) {
           if (flags & MI_CHECK_NONNEG) bad |= MI_IDERR_RANGE;
@@ -109,10 +110,14 @@ __global__ __launch_bounds__(EMBAG_BLOCK) void embag_fwd_kernel(
     Acc<VEC> r[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const int64_t row = ok[u] ? (base + id[u]) : base;
-      if (ok[u]) {
-        ld_row<VEC>(wcol + row * dim, r[u]);
-      } else {
+      // no branch around the load (the compiler waits for all outstanding loads where such a branch joins):
+      // an entry without a valid id reads row 0 of the array and is zeroed afterwards
+      const int64_t row = ok[u] ? (base + id[u]) : 0;
+      ld_row<VEC>(wcol + row * dim, r[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (!ok[u]) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) r[u].v[k] = 0.f;
       }
@@ -157,10 +162,11 @@ __global__ __launch_bounds__(EMBAG_BLOCK) void embag_fwd_l1_kernel(
   const int bag0 = blockIdx.x * groups * L1_ROWS;
   int64_t id[L1_ROWS];
   int bag[L1_ROWS], tt[L1_ROWS];
+  bool okv[L1_ROWS];
 #pragma unroll
   for (int u = 0; u < L1_ROWS; ++u) {
     bag[u] = bag0 + u * groups + sub;
-    id[u] = bag[u] < n_bags ? mi_ld_id<IDX>(indices, bag[u]) : (int64_t) -1;
+    id[u] = mi_ld_id<IDX>(indices, bag[u] < n_bags ? bag[u] : 0);   // no branch around the load; masked below
   }
   int bad = 0;
   Acc<4> r[L1_ROWS];
@@ -169,8 +175,8 @@ __global__ __launch_bounds__(EMBAG_BLOCK) void embag_fwd_l1_kernel(
     const int b = bag[u] / T;
     tt[u] = bag[u] - b * T;
     const bool present = bag[u] < n_bags;
-    const int64_t base = present ? toffs[tt[u]] : 0;
-    const int64_t rows = present ? toffs[tt[u] + 1] - base : 0;
+    const int64_t base = toffs[tt[u]];          // tt < T whatever the bag number
+    const int64_t rows = toffs[tt[u] + 1] - base;
     if (present) {
       if (id[u] < 0) {
         if (flags & MI_CHECK_NONNEG) bad |= MI_IDERR_RANGE;
@@ -178,9 +184,13 @@ __global__ __launch_bounds__(EMBAG_BLOCK) void embag_fwd_l1_kernel(
         bad |= MI_IDERR_RANGE;
       }
     }
-    if (present && id[u] >= 0 && id[u] < rows) {
-      ld_row<4>(weights + (base + id[u]) * dim + (int64_t) c * 4, r[u]);
-    } else {
+    okv[u] = present && id[u] >= 0 && id[u] < rows;
+    // the row load carries no branch: a bag without a valid id reads row 0 of the array and is zeroed below
+    ld_row<4>(weights + (okv[u] ? base + id[u] : 0) * dim + (int64_t) c * 4, r[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < L1_ROWS; ++u) {
+    if (!okv[u]) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) r[u].v[k] = 0.f;
     }

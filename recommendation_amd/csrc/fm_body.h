@@ -66,8 +66,11 @@ __device__ __forceinline__ void fm_fwd_body(const FmFwdArgs& a, int vblock, int 
       const int fs = present ? f : 0;
       const int64_t id = mi_ld_id<IDX>(ids, a.ids_tm ? (int64_t) fs * B + gid : (int64_t) gid * T + fs);
       const int64_t base = toffs[fs];
-      const int64_t rows = toffs[fs + 1] - base;
-      ok[u] = present && id >= 0 && id < rows;  // FM has no padding id: every field carries one id
+      const int64_t next = toffs[fs + 1];
+      // (bitwise &: with && the load of toffs[fs + 1] is only made when the id is present and non-negative,
+      // i.e. behind a branch, and the compiler waits for all outstanding loads where that branch joins -
+      // the eight fields of a lane became eight dependent round trips)
+      ok[u] = present & (id >= 0) & (id < next - base);  // FM has no padding id: every field carries one id
       if (present && !ok[u]) bad |= MI_IDERR_RANGE;
       row[u] = ok[u] ? base + id : 0;
     }
@@ -77,13 +80,13 @@ __device__ __forceinline__ void fm_fwd_body(const FmFwdArgs& a, int vblock, int 
     for (int u = 0; u < UF; ++u) {
       const float* r = rec + row[u] * tab.stride;
       v[u] = *reinterpret_cast<const float4*>(r + c * 4);
-      w[u] = (c == 0) ? r[tab.off_w1] : 0.f;
+      w[u] = r[tab.off_w1];  // every lane of the row (same word: no extra traffic); only lane c == 0 adds it below
     }
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
       const float4 x = make_float4(ok[u] ? v[u].x : 0.f, ok[u] ? v[u].y : 0.f, ok[u] ? v[u].z : 0.f,
                                    ok[u] ? v[u].w : 0.f);
-      lin += ok[u] ? w[u] : 0.f;
+      lin += (ok[u] && c == 0) ? w[u] : 0.f;
       s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
       sq.x = fmaf(x.x, x.x, sq.x); sq.y = fmaf(x.y, x.y, sq.y);
       sq.z = fmaf(x.z, x.z, sq.z); sq.w = fmaf(x.w, x.w, sq.w);
@@ -160,27 +163,37 @@ __device__ __forceinline__ void fm_dense_body(const FmDenseArgs& a, int j, float
     pp = a.dp[j];
     if (a.lr_dev) plr = a.lr_dev[0];
   }
+  // The mode is decided ONCE per workgroup and each loop body is free of branches around its loads: where
+  // control flow joins behind a load the compiler waits for every outstanding load, which turned the 16
+  // requests of a round into 16 dependent round trips.
   float acc = 0.f;
-  for (int64_t b0 = threadIdx.x; b0 < a.B; b0 += (int64_t) UR * NT) {
-    float x[UR], y[UR];
+  if (j < a.n_dense) {
+    const float* __restrict__ gp = a.g;
+    const float* __restrict__ dp_ = a.dense + j;
+    for (int64_t b0 = threadIdx.x; b0 < a.B; b0 += (int64_t) UR * NT) {
+      float x[UR], y[UR];
 #pragma unroll
-    for (int u = 0; u < UR; ++u) {
-      const int64_t b = b0 + (int64_t) u * NT;
-      const int64_t bs = b < a.B ? b : b0;
-      if (j < a.n_dense) {
-        x[u] = a.g[bs * a.g_ld];
-        y[u] = a.dense[bs * a.dense_ld + j];
-      } else if (j == a.n_dense) {
-        x[u] = a.g[bs * a.g_ld];
-        y[u] = 1.0f;
-      } else {
-        x[u] = a.loss_rows[bs * a.loss_ld];
-        y[u] = 1.0f;
+      for (int u = 0; u < UR; ++u) {
+        const int64_t b = b0 + (int64_t) u * NT;
+        const int64_t bs = b < a.B ? b : b0;
+        x[u] = gp[bs * a.g_ld];
+        y[u] = dp_[bs * a.dense_ld];
       }
-    }
 #pragma unroll
-    for (int u = 0; u < UR; ++u) {
-      if (b0 + (int64_t) u * NT < a.B) acc = (j < a.n_dense) ? fmaf(x[u], y[u], acc) : acc + x[u];
+      for (int u = 0; u < UR; ++u) acc = (b0 + (int64_t) u * NT < a.B) ? fmaf(x[u], y[u], acc) : acc;
+    }
+  } else {
+    const float* __restrict__ src = j == a.n_dense ? a.g : a.loss_rows;
+    const int64_t ld = j == a.n_dense ? a.g_ld : a.loss_ld;
+    for (int64_t b0 = threadIdx.x; b0 < a.B; b0 += (int64_t) UR * NT) {
+      float x[UR];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const int64_t b = b0 + (int64_t) u * NT;
+        x[u] = src[(b < a.B ? b : b0) * ld];
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) acc = (b0 + (int64_t) u * NT < a.B) ? acc + x[u] : acc;
     }
   }
   sh[threadIdx.x] = acc;

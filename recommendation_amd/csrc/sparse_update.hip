@@ -141,7 +141,8 @@ struct RowsGradSrc {
 };
 
 // FM: entry of sample b contributes g[b]*S[b] (vector) and g[b] (scalar); bag_len == 1.
-// The sample of entry p is p / T, or entry_sample[p] when given (sharded tables: the entries an
+// The sample of entry p is p / T (a caller with another entry -> sample map sorts with T = 1 and makes the
+// sample the sort's payload, as the sharded owner launch does: the entries an
 // owner received from all ranks, each tagged with its requester's sample).
 struct FmSrc {
   // (measured with two rows per round on the distinct-row waves of the FM step: no change, 24.4 vs 24.1 us)
@@ -149,10 +150,9 @@ struct FmSrc {
   const float* g;
   const float* S;
   int g_ld, S_ld;  // floats between consecutive samples (1 and dim when g and S are separate arrays)
-  const int32_t* entry_sample;
   template <int VEC>
   __device__ __forceinline__ void load(const PlanDev& pl, int p, int c, float* o, float& sc) const {
-    const int b = entry_sample ? entry_sample[p] : p / pl.T;
+    const int b = p / pl.T;
     const float gb = g[(int64_t) b * g_ld];
     ldv<VEC>(S + (int64_t) b * S_ld + c * VEC, o);
 #pragma unroll
@@ -284,7 +284,9 @@ struct FmUpd {
   __device__ __forceinline__ void load(int64_t row, int c, Regs<VEC>& r) const {
     const float* rec = t.rec + row * t.stride;
     opt_load<OPT, VEC>(rec, rec + t.off_vs0, rec + t.off_vs1, c, r.v);
-    if (c == 0) opt_load<OPT, 1>(rec + t.off_w1, rec + t.off_ws0, rec + t.off_ws1, 0, r.w);
+    // every lane loads the first-order weight and its state (the lanes of a row read the same words: no extra
+    // traffic); a branch for lane 0 alone would make the compiler wait for all outstanding loads behind it
+    opt_load<OPT, 1>(rec + t.off_w1, rec + t.off_ws0, rec + t.off_ws1, 0, r.w);
   }
   template <int VEC>
   __device__ __forceinline__ void finish(int64_t row, int c, int lanes, Regs<VEC>& r, const float* acc,
@@ -1326,7 +1328,8 @@ static int fm_bwd_apply_impl(const char* who, const mi_bwd_plan* plan, const mi_
   Geometry geo;
   rc = geometry(tab->dim, true, &geo);
   if (rc) return rc;
-  FmSrc src{g, S, g_ld, S_ld, entry_sample};
+  MI_REQUIRE(!entry_sample, "%s: entry_sample is no longer taken; sort with T = 1 and the sample as payload", who);
+  FmSrc src{g, S, g_ld, S_ld};
   OptArgs a{lr, beta1, beta2, eps, lr_dev};
   hipStream_t s = (hipStream_t) stream;
   switch (opt) {

@@ -282,17 +282,27 @@ __device__ __forceinline__ void table_sort_body(int t, int part, int parts, cons
   // local key: the id, or `rows` (one past the largest) for a padding / out-of-range entry;
   // image 0 when the workgroup sorts the whole table, image 1 (scratch) when it first selects
   const int first = parts > 1 ? 1 : 0;
+  // all of a thread's ids are requested before the first is used: the loads carry no branch around them
+  // (entries past n re-read entry 0; where control flow joins behind a load the compiler waits for every
+  // outstanding load, which made these eight loads eight dependent round trips)
+  int64_t idv[TS_ITEMS];
+  int pv[TS_ITEMS];
+#pragma unroll
+  for (int k = 0; k < TS_ITEMS; ++k) {
+    const int e = k * TS_THREADS + tid;
+    const int es = e < n ? e : 0;
+    const int b = es / bag_len;
+    pv[k] = (b * T + t) * bag_len + (es - b * bag_len);
+    // table-major ids (bag_len 1): the table's ids are one contiguous run, a full-line load per wave
+    // instead of one line per id
+    idv[k] = mi_ld_id<IDX>(indices, ids_tm ? (int64_t) t * n + es : (int64_t) pv[k]);
+  }
 #pragma unroll
   for (int k = 0; k < TS_ITEMS; ++k) {
     const int e = k * TS_THREADS + tid;
     if (e < n) {
-      const int b = e / bag_len;
-      const int p = (b * T + t) * bag_len + (e - b * bag_len);
-      // table-major ids (bag_len 1): the table's ids are one contiguous run, a full-line load per wave
-      // instead of one line per id
-      const int64_t id = mi_ld_id<IDX>(indices, ids_tm ? (int64_t) t * n + e : (int64_t) p);
-      kbuf[first][e] = (id >= 0 && id < (int64_t) rows) ? (uint32_t) id : rows;
-      vbuf[first][e] = (uint32_t) p;
+      kbuf[first][e] = (idv[k] >= 0 && idv[k] < (int64_t) rows) ? (uint32_t) idv[k] : rows;
+      vbuf[first][e] = (uint32_t) pv[k];
     }
   }
   int m, out_base;  // entries this workgroup sorts, and where its output starts in the table's block
