@@ -54,8 +54,10 @@ def parse_args():
                          '(measured slower at world size 1: the extra stream hops cost more than the exchange they hide)')
     ap.add_argument('--din-full-rows', action='store_true',
                     help='DIN: materialise the full [q | k | q-k | q*k] rows instead of the factored first layer')
-    ap.add_argument('--no-prefetch-sort', action='store_true',
-                    help='single-GPU step: sort this batch\'s ids inside the step instead of beside the previous step')
+    ap.add_argument('--prefetch-sort', action='store_true',
+                    help='single-GPU step: sort the next batch\'s ids on a side stream beside this step instead of inside '
+                         'the next one (bit-identical; measured slower at B = 8192: the stream hops and the third launch '
+                         'cost more than the sort they hide)')
     ap.add_argument('--ids-sample-major', action='store_true',
                     help='feed the single-GPU step ids as [B][T] only (default: also one [B] row per field)')
     ap.add_argument('--force-sharded', action='store_true',
@@ -932,7 +934,7 @@ def main():
     # one id tensor per field, stored field after field ([T][B]): the layout the two-launch step sorts fastest
     tms = [b[0].t().contiguous() for b in batches] if (not sharded and not args.ids_sample_major) else None
     kws = [dict(kw, ids_tm=tms[j]) if tms else kw for j in range(len(batches))]
-    prefetch_sort = not sharded and not args.no_prefetch_sort and B <= model._fused_max
+    prefetch_sort = not sharded and args.prefetch_sort and B <= model._fused_max
     if prefetch_sort:
         # a training loop knows its next batch: its ids are sorted beside this step (the sort needs nothing else)
         nb = len(batches)
