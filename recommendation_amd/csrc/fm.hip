@@ -33,23 +33,24 @@ __global__ __launch_bounds__(256) void fm_fwd_kernel(FmFwdArgs a, float* __restr
   fm_fwd_body<IDX, DIM>(a, blockIdx.x, 256);
 }
 
-// One launch for everything of a step that needs only its inputs: workgroup t < T sorts table t's
-// (row, position) pairs in LDS, the others run the forward, and one thread advances the optimizer
-// schedule (its consumers run in later launches).  The two halves do not depend on each other, so
-// the launch lasts as long as the longer one instead of their sum.
+// One launch for everything of a step that needs only its inputs: the first fwd_blocks workgroups
+// run the forward, the following ones sort the tables' (row, position) pairs in LDS (up to `parts`
+// per table), and one thread advances the optimizer schedule (its consumers run in later launches).
+// The two halves do not depend on each other, so the launch lasts as long as the longer one instead
+// of their sum.
 template <typename IDX, int DIM>
-__global__ __launch_bounds__(TS_THREADS) void fm_fwd_sort_kernel(FmFwdArgs a, int parts, uint32_t sentinel,
-                                                                uint32_t* __restrict__ sorted_rows,
+__global__ __launch_bounds__(TS_THREADS) void fm_fwd_sort_kernel(FmFwdArgs a, int fwd_blocks, int parts,
+                                                                uint32_t sentinel, uint32_t* __restrict__ sorted_rows,
                                                                 uint32_t* __restrict__ perm, float* __restrict__ sched,
                                                                 float lr, float b1, float b2) {
-  const int sort_blocks = a.T * parts;
-  if ((int) blockIdx.x < sort_blocks) {
-    table_sort_body<IDX>(blockIdx.x / parts, blockIdx.x % parts, parts, a.toffs, a.T, a.ids, 1, a.B, sentinel,
-                         sorted_rows, perm, a.ids_tm != 0);
+  if ((int) blockIdx.x >= fwd_blocks) {
+    int t, part, np;
+    if (!ts_assign(a.toffs, a.T, a.B, parts, (int) blockIdx.x - fwd_blocks, t, part, np)) return;
+    table_sort_body<IDX>(t, part, np, a.toffs, a.T, a.ids, 1, a.B, sentinel, sorted_rows, perm, a.ids_tm != 0);
     return;
   }
-  if (sched && (int) blockIdx.x == sort_blocks && threadIdx.x == 0) adam_schedule_body(sched, lr, b1, b2);
-  fm_fwd_body<IDX, DIM>(a, blockIdx.x - sort_blocks, TS_THREADS);
+  if (sched && blockIdx.x == 0 && threadIdx.x == 0) adam_schedule_body(sched, lr, b1, b2);
+  fm_fwd_body<IDX, DIM>(a, blockIdx.x, TS_THREADS);
 }
 
 // The per-table sort on its own, for ids in either layout.
@@ -58,8 +59,9 @@ __global__ __launch_bounds__(TS_THREADS) void fm_sort_kernel(const int64_t* __re
                                                             const void* __restrict__ ids, int B, int parts,
                                                             uint32_t sentinel, uint32_t* __restrict__ sorted_rows,
                                                             uint32_t* __restrict__ perm, int ids_tm) {
-  table_sort_body<IDX>(blockIdx.x / parts, blockIdx.x % parts, parts, toffs, T, ids, 1, B, sentinel, sorted_rows, perm,
-                       ids_tm != 0);
+  int t, part, np;
+  if (!ts_assign(toffs, T, B, parts, (int) blockIdx.x, t, part, np)) return;
+  table_sort_body<IDX>(t, part, np, toffs, T, ids, 1, B, sentinel, sorted_rows, perm, ids_tm != 0);
 }
 
 __global__ __launch_bounds__(FM_DENSE_THREADS) void fm_dense_kernel(FmDenseArgs a) {
@@ -87,7 +89,7 @@ int launch_fm(const FmFwdArgs& a, uint32_t sentinel, uint32_t* sorted_rows, uint
       const int fwd_blocks_ = (int) mi_cdiv(a.B, TS_THREADS / G_);                                                  \
       const int parts_ = mi_table_sort_parts(a.T, a.B, fwd_blocks_);                                                \
       hipLaunchKernelGGL((fm_fwd_sort_kernel<IDX, D>), dim3((unsigned) (a.T * parts_ + fwd_blocks_)),               \
-                         dim3(TS_THREADS), 0, s, a, parts_, sentinel, sorted_rows, perm, sched, lr, b1, b2);        \
+                         dim3(TS_THREADS), 0, s, a, fwd_blocks_, parts_, sentinel, sorted_rows, perm, sched, lr, b1, b2);        \
     }                                                                                                               \
     break;                                                                                                          \
   }
@@ -272,3 +274,9 @@ extern "C" int mi_fm_dense_step_rows(const float* X, int ld, int dim, int n_dens
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
+
+#ifdef TS_TRACE
+extern "C" int mi_debug_ts_trace(unsigned long long* host_out, int n) {
+  return (int) hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ts_trace_buf), (size_t) n * 8);
+}
+#endif

@@ -876,7 +876,7 @@ extern "C" int mi_shard_owner_fwd_sort(const mi_fm_table* tab, int64_t local_row
   case D: {                                                                                                         \
     constexpr int G_ = (D / 4) > 16 ? (D / 4) : 16;                                                                 \
     const int fwd_blocks_ = (int) mi_cdiv(bags, TS_THREADS / G_);                                                   \
-    const int parts_ = sorted_rows ? mi_table_sort_parts(T, (int) B, 0) : 0;                                        \
+    const int parts_ = sorted_rows ? (mi_table_sort_parts(T, (int) B, 0) < 4 ? mi_table_sort_parts(T, (int) B, 0) : 4) : 0;                                        \
     hipLaunchKernelGGL((owner_fwd_sort_kernel<D>), dim3((unsigned) (T * parts_ + fwd_blocks_)), dim3(TS_THREADS),   \
                        lds, s, a, parts_, sorted_rows, reinterpret_cast<uint32_t*>(perm), n_total, sched, lr, beta1, \
                        beta2);                                                                                      \

@@ -404,7 +404,9 @@ __global__ __launch_bounds__(TS_THREADS) void table_sort_kernel(const int64_t* _
                                                                int n, int parts, uint32_t sentinel,
                                                                uint32_t* __restrict__ sorted_rows,
                                                                uint32_t* __restrict__ perm) {
-  table_sort_body<IDX>(blockIdx.x / parts, blockIdx.x % parts, parts, toffs, T, indices, bag_len, n, sentinel,
+  int t, part, np;
+  if (!ts_assign(toffs, T, n, parts, (int) blockIdx.x, t, part, np)) return;
+  table_sort_body<IDX>(t, part, np, toffs, T, indices, bag_len, n, sentinel,
                        sorted_rows, perm);
 }
 

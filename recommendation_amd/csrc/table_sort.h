@@ -11,13 +11,20 @@
 // back in row order, so concatenating the per-table results IS the global sort by
 // (row, position); padding / invalid entries end each table's block as sentinels.
 //
-// A table may be shared by `parts` workgroups without any communication between them: every one
-// reads all the table's ids, histograms their top 8 key bits, cuts the 256 bins into `parts`
-// contiguous ranges of about equal population (the same cut in every workgroup, it only depends
-// on the data), keeps the entries of ITS range in their original order, sorts those, and writes
-// them where they belong: behind the entries of the lower ranges, whose number it knows from the
-// histogram.  The ranking work, which dominates, drops by the number of parts for evenly spread
-// keys; a single over-full bin cannot be cut, so a heavily skewed table gains less.
+// A table may be shared by `parts` workgroups without any communication between them.  Every one
+// reads all the table's ids and 64 evenly spaced samples of them, ranks the samples (the same
+// ranking in every workgroup, it only depends on the data) and takes the samples of rank
+// 64*q/parts as cuts of the order (key, position).  Positions are distinct, so whatever the keys
+// are - even all equal - the cuts divide the table into about equal parts.  The workgroup keeps
+// the entries between ITS two cuts in their original order, sorts those by key, and writes them
+// behind the entries below its lower cut, which it counted while selecting.  The ranking work,
+// which dominates, drops by the number of parts.
+#ifdef TS_TRACE
+static __device__ unsigned long long ts_trace_buf[1024 * 16];
+#define TS_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0) ts_trace_buf[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define TS_MARK(i) do {} while (0)
+#endif
 constexpr int TS_THREADS = 1024;
 constexpr int TS_WAVES = TS_THREADS / MI_WAVE;
 constexpr int TS_ITEMS = 8;
@@ -25,17 +32,22 @@ constexpr int TS_MAX = TS_THREADS * TS_ITEMS;  // 8192 entries per table
 constexpr int TS_RADIX = 256;
 constexpr int TS_PARTS_MAX = 8;
 
-// How many workgroups share a table: up to 4 once a table has enough entries to make the split
-// worth its extra pass over the ids, as long as all of them (plus `other_blocks` workgroups of the
-// same launch) still fit the chip's 256 CUs at one workgroup per CU.
+// How many workgroups are launched per table: up to TS_PMAX once a table has enough entries to make
+// sharing worth its extra pass over the ids.  Only tables of more than 65535 rows use them all (see
+// table_sort_body), the others' spare workgroups leave at once; about half are taken to stay, and
+// those (plus `other_blocks` workgroups of the same launch) should fit the chip's 256 CUs at one
+// workgroup per CU.
+#ifndef TS_PMAX
+#define TS_PMAX 8
+#endif
 static inline int mi_table_sort_parts(int T, int per_table, int other_blocks) {
-  int parts = per_table >= 4096 ? 4 : (per_table >= 2048 ? 2 : 1);
-  while (parts > 1 && T * parts + other_blocks > 248) parts >>= 1;
+  int parts = per_table >= 4096 ? TS_PMAX : (per_table >= 2048 ? 2 : 1);
+  while (parts > 1 && T * parts / 2 + other_blocks > 248) parts >>= 1;
   return parts;
 }
 
 // The LDS arrays of a sorting workgroup (152 KB: one workgroup per CU).
-struct TsLds {
+struct alignas(16) TsLds {
   uint32_t kbuf[2][TS_MAX];
   uint32_t vbuf[2][TS_MAX];
   uint32_t cnt[TS_WAVES][TS_RADIX];
@@ -43,225 +55,158 @@ struct TsLds {
   uint32_t qsum[4][TS_RADIX];
   uint32_t wsum[TS_WAVES];
   int cut[2];
+  unsigned long long cut64[2];
+  uint32_t wsel[TS_WAVES][2];
 };
 
+// Inclusive prefix sum over the 64 lanes of a wave, all lanes active, in six data-parallel-primitive
+// adds (shifts inside rows of 16 lanes, then the last lane of a row broadcast into the following
+// rows) instead of six round trips through the LDS permute path.
+__device__ __forceinline__ uint32_t ts_wave_scan(uint32_t x) {
+  int v = (int) x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return (uint32_t) v;
+}
+
 // Stable LSD radix sort of the m <= TS_MAX (key, value) pairs in L.kbuf[cur] / L.vbuf[cur] by the low
-// 8*passes key bits, entirely in LDS; returns the image that holds the result.  All TS_THREADS
-// threads call this; the caller's fill needs no barrier of its own (the first pass has one) and
-// the result is visible to every thread on return.
-__device__ __forceinline__ int ts_lds_sort(TsLds& L, int m, int passes, int cur) {
+// `bits` key bits (8 per pass), entirely in LDS; returns the image that holds the result.  All
+// TS_THREADS threads call this; the caller's fill needs no barrier of its own and the result is
+// visible to every thread on return.
+//
+// A pass has three phases and three barriers.  (1) Every wave ranks its own slice: lanes with the
+// same digit find each other by ballots, the counts go to the wave's own row of cnt, which the wave
+// itself cleared (no barrier between the clear and the ranking).  (2) ONE wave turns the 16 x 256
+// counts into scatter bases: lane l owns digits 4l..4l+3, reads them for every wave with 128-bit
+// loads, and needs nothing but a wave scan to know every base.  (3) Every wave scatters its
+// entries.  A chain of small cooperative scans here used to cost three more barriers a pass, and
+// at two entries per thread the barriers and the LDS round trips between them were the whole cost.
+__device__ __forceinline__ int ts_lds_sort_bits(TsLds& L, int m, int bits, int cur) {
   auto& kbuf = L.kbuf;
   auto& vbuf = L.vbuf;
   auto& cnt = L.cnt;
-  auto& dbase = L.dbase;
-  auto& qsum = L.qsum;
-  auto& wsum = L.wsum;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  // the m entries are spread over all waves: `items` per thread, wave w owns [w*64*items, (w+1)*64*items)
-  const int items = (m + TS_THREADS - 1) / TS_THREADS;
-  const int wbase = w * MI_WAVE * items;
-  for (int pass = 0; pass < passes && m > 0; ++pass) {
-    const int shift = pass * 8;
-    for (int i = tid; i < TS_WAVES * TS_RADIX; i += TS_THREADS) (&cnt[0][0])[i] = 0;
-    __syncthreads();  // also covers the initial fill / the previous pass's scatter
+  // the m entries are spread over the waves in slices of whole 64-entry groups: every wave takes m / TS_THREADS
+  // groups and the last waves one more, so no SIMD ranks a group more than it must
+  // (the LAST waves: wave 0 has the scan below to itself)
+  const int items_lo = m / TS_THREADS, extra_waves = (m - items_lo * TS_THREADS + MI_WAVE - 1) / MI_WAVE;
+  const int first_extra = TS_WAVES - extra_waves;
+  const int items = items_lo + (w >= first_extra ? 1 : 0);  // uniform over the wave
+  const int wbase = MI_WAVE * (w * items_lo + (w >= first_extra ? w - first_extra : 0));
+  __syncthreads();  // the caller's fill
+  for (int shift = 0; shift < bits && m > 0; shift += 8) {
+    const int nb = bits - shift < 8 ? bits - shift : 8;  // digit bits that can be set in this pass
+    *reinterpret_cast<uint4*>(&cnt[w][4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
     // rank inside the wave's slice (entry j of lane l: slice + j*64 + l)
-    uint32_t key[TS_ITEMS], loc[TS_ITEMS];
+    uint32_t key[TS_ITEMS], val[TS_ITEMS], loc[TS_ITEMS];
 #pragma unroll
     for (int j = 0; j < TS_ITEMS; ++j) {
-      if (j >= items) break;  // uniform over the workgroup
+      if (j >= items) break;
       const int e = wbase + j * MI_WAVE + lane;
       const bool valid = e < m;
       key[j] = valid ? kbuf[cur][e] : 0xFFFFFFFFu;
+      val[j] = valid ? vbuf[cur][e] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < TS_ITEMS; ++j) {
+      if (j >= items) break;
+      const bool valid = wbase + j * MI_WAVE + lane < m;
       const uint32_t d = (key[j] >> shift) & (TS_RADIX - 1);
-      // lanes holding the same digit: AND over the 8 digit bits of "lanes whose bit equals mine".
+      // lanes holding the same digit: AND over the digit bits of "lanes whose bit equals mine".
       // x = 0 / ~0 (bit clear / set), so ~(ballot ^ x) is that set; the two 32-bit halves are kept
       // apart (sign-extending bit extract, xnor, and: 6 vector instructions per bit).
       const unsigned long long vb = __ballot(valid);
       uint32_t mlo = (uint32_t) vb, mhi = (uint32_t) (vb >> 32);
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
-        const int x = ((int) (d << (31 - b))) >> 31;
-        const unsigned long long bl = __ballot(x != 0);
+        if (b >= nb) break;  // uniform
+        int x;  // (written out: the compiler's own form is a shift, a compare and a second shift)
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(x) : "v"(d), "n"(b));
+        const unsigned long long bl = __builtin_amdgcn_ballot_w64(x != 0);
         mlo &= ~((uint32_t) bl ^ (uint32_t) x);
         mhi &= ~((uint32_t) (bl >> 32) ^ (uint32_t) x);
       }
-      const uint32_t before = (uint32_t) (__popc(mlo & (uint32_t) lt) + __popc(mhi & (uint32_t) (lt >> 32)));
+      const uint32_t before = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));  // same-digit lanes below mine
       const uint32_t old = cnt[w][d];
       if (valid && before == 0) cnt[w][d] = old + (uint32_t) (__popc(mlo) + __popc(mhi));
       loc[j] = old + before;
     }
     __syncthreads();
-    // digit totals -> per-wave running bases, then an exclusive scan of the 256 totals
-    // thread (q, d) = (tid >> 8, tid & 255) scans waves 4q..4q+3 of digit d; the four partial
-    // totals of a digit are then chained through LDS
-    uint32_t partial = 0;
-    {
-      const int dq = tid & (TS_RADIX - 1), q4 = (tid >> 8) * 4;
+    if (w == 0) {
+      // cnt[ww][d] <- entries that precede wave ww's first entry of digit d: all entries of lower
+      // digits, and those of digit d in lower waves
+      uint4 c[TS_WAVES];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t c = cnt[q4 + i][dq];
-        cnt[q4 + i][dq] = partial;
-        partial += c;
+      for (int ww = 0; ww < TS_WAVES; ++ww) c[ww] = *reinterpret_cast<const uint4*>(&cnt[ww][4 * lane]);
+      uint4 run = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int ww = 0; ww < TS_WAVES; ++ww) {
+        const uint4 x = c[ww];
+        c[ww] = run;
+        run.x += x.x; run.y += x.y; run.z += x.z; run.w += x.w;
       }
-      qsum[tid >> 8][dq] = partial;
+      const uint32_t mine = run.x + run.y + run.z + run.w;
+      const uint32_t inc = ts_wave_scan(mine);
+      const uint32_t b0 = inc - mine, b1 = b0 + run.x, b2 = b1 + run.y, b3 = b2 + run.z;
+#pragma unroll
+      for (int ww = 0; ww < TS_WAVES; ++ww)
+        *reinterpret_cast<uint4*>(&cnt[ww][4 * lane]) = make_uint4(c[ww].x + b0, c[ww].y + b1, c[ww].z + b2, c[ww].w + b3);
     }
     __syncthreads();
-    uint32_t total = 0;
-    {
-      const int dq = tid & (TS_RADIX - 1), q = tid >> 8;
-      uint32_t before_q = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t c = qsum[i][dq];
-        if (i < q) before_q += c;
-        total += c;
-      }
-      const int q4 = q * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) cnt[q4 + i][dq] += before_q;
-      if (tid >= TS_RADIX) total = 0;
-    }
-    uint32_t inc = total;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t x = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += x;
-    }
-    if (tid < TS_RADIX && lane == 63) wsum[w] = inc;
-    __syncthreads();
-    if (tid < TS_RADIX) {
-      uint32_t wb = 0;
-      for (int i = 0; i < w; ++i) wb += wsum[i];
-      dbase[tid] = wb + inc - total;
-    }
-    __syncthreads();
-    uint32_t val[TS_ITEMS];
-#pragma unroll
-    for (int j = 0; j < TS_ITEMS; ++j) {
-      if (j >= items) break;
-      const int e = wbase + j * MI_WAVE + lane;
-      val[j] = e < m ? vbuf[cur][e] : 0u;
-    }
 #pragma unroll
     for (int j = 0; j < TS_ITEMS; ++j) {
       if (j >= items) break;
       const int e = wbase + j * MI_WAVE + lane;
       if (e < m) {
         const uint32_t d = (key[j] >> shift) & (TS_RADIX - 1);
-        const uint32_t pos = dbase[d] + cnt[w][d] + loc[j];
+        const uint32_t pos = cnt[w][d] + loc[j];
         kbuf[cur ^ 1][pos] = key[j];
         vbuf[cur ^ 1][pos] = val[j];
       }
     }
     cur ^= 1;
-    __syncthreads();  // the scatter is complete (and cnt / dbase free) before the next pass
+    __syncthreads();  // the scatter is complete (and cnt free) before the next pass
+    TS_MARK(4 + (shift >> 3));
   }
   return cur;
 }
 
-// The n <= TS_MAX (key, value) pairs of a table lie in image `parts > 1 ? 1 : 0` of L, keys below
-// 2^bits.  Sorts part `part` of `parts` of them (see above) into the returned image, entries
-// [0, m); out_base = how many entries of the table sort before this part's.  All threads call this.
-__device__ __forceinline__ int ts_sort_part(TsLds& L, int n, int part, int parts, int bits, int& m_out,
-                                            int& out_base_out) {
-  auto& kbuf = L.kbuf;
-  auto& vbuf = L.vbuf;
-  auto& dbase = L.dbase;
-  auto& qsum = L.qsum;
-  auto& wsum = L.wsum;
-  auto& cut = L.cut;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int passes = (bits + 7) / 8;
-  int m = n, out_base = 0;  // entries this workgroup sorts, and where its output starts in the table's block
-  if (parts > 1) {
-    const int top = bits > 8 ? bits - 8 : 0;  // bin = key >> top, 0..255
-    if (tid < TS_RADIX) dbase[tid] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < TS_ITEMS; ++k) {
-      const int e = k * TS_THREADS + tid;
-      if (e < n) atomicAdd(&dbase[kbuf[1][e] >> top], 1u);  // integer counts: the order of the adds does not matter
+__device__ __forceinline__ int ts_lds_sort(TsLds& L, int m, int passes, int cur) {
+  return ts_lds_sort_bits(L, m, passes * 8, cur);
+}
+
+// Which table, and which part of it, sort slot `slot` of a launch with parts_max slots per table works
+// on.  A table whose keys need fewer passes is shared by fewer workgroups: the passes are what
+// sharing shortens, reading and selecting the ids costs the same in every part.  The slots in use
+// come first, so the workgroups of the unused ones (for which this returns false) are the last of
+// the launch and leave at once.  Every wave works it out for itself, lane l looking at table l: one
+// round trip for the offsets and a wave scan, instead of a loop of T dependent scalar loads.
+__device__ __forceinline__ bool ts_assign(const int64_t* __restrict__ toffs, int T, int n, int parts_max, int slot,
+                                          int& t_out, int& part_out, int& parts_out) {
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  int base = 0;
+  for (int t0 = 0; t0 < T; t0 += MI_WAVE) {  // lane l looks at table t0 + l
+    const int tt = t0 + lane, tc = tt < T ? tt : T - 1;
+    const uint32_t rows = (uint32_t) (toffs[tc + 1] - toffs[tc]);
+    int want = (n < MI_WAVE || parts_max == 1) ? 1
+               : (rows > 65535u ? parts_max : (rows > 255u ? (parts_max + 1) / 2 : (parts_max + 3) / 4));
+    if (tt >= T) want = 0;
+    const int inc = (int) ts_wave_scan((uint32_t) want);
+    const int total = __builtin_amdgcn_readlane(inc, MI_WAVE - 1);
+    if (slot < base + total) {
+      const int l = __popcll(__ballot(base + inc <= slot));  // tables that end at or before the slot
+      t_out = t0 + l;
+      parts_out = __builtin_amdgcn_readlane(want, l);
+      part_out = slot - base - __builtin_amdgcn_readlane(inc - want, l);
+      return true;
     }
-    __syncthreads();
-    // exclusive prefix of the 256 bin counts -> qsum[0][bin]
-    uint32_t c = tid < TS_RADIX ? dbase[tid] : 0u, inc = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t x = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += x;
-    }
-    if (tid < TS_RADIX && lane == 63) wsum[w] = inc;
-    __syncthreads();
-    if (tid < TS_RADIX) {
-      uint32_t wb = 0;
-      for (int i = 0; i < w; ++i) wb += wsum[i];
-      qsum[0][tid] = wb + inc - c;
-    }
-    __syncthreads();
-    // range q starts at the last bin whose prefix does not exceed q*n/parts (bin 0 for q = 0)
-    if (tid < TS_RADIX) {
-      const uint32_t mine = qsum[0][tid], next = tid + 1 < TS_RADIX ? qsum[0][tid + 1] : 0xFFFFFFFFu;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int q = part + s;
-        if (q > 0 && q < parts) {
-          const uint32_t target = (uint32_t) (((int64_t) q * n) / parts);
-          if (mine <= target && next > target) cut[s] = tid;
-        }
-      }
-    }
-    if (tid == 0) {
-      if (part == 0) cut[0] = 0;
-      if (part == parts - 1) cut[1] = TS_RADIX;
-    }
-    __syncthreads();
-    const int b_lo = cut[0], b_hi = cut[1];
-    out_base = (int) qsum[0][b_lo];
-    m = (b_hi == TS_RADIX ? n : (int) qsum[0][b_hi]) - out_base;
-    // stable selection: entry e of the table keeps its place among the selected ones
-    unsigned long long bal[TS_ITEMS];
-    uint32_t key[TS_ITEMS];
-    const int wbase = w * (MI_WAVE * TS_ITEMS);
-#pragma unroll
-    for (int j = 0; j < TS_ITEMS; ++j) {
-      const int e = wbase + j * MI_WAVE + lane;
-      key[j] = e < n ? kbuf[1][e] : 0u;
-      const int bin = (int) (key[j] >> top);
-      bal[j] = __ballot(e < n && bin >= b_lo && bin < b_hi);
-      if (lane == 0) qsum[1][w * TS_ITEMS + j] = (uint32_t) __popcll(bal[j]);
-    }
-    __syncthreads();
-    if (tid < TS_WAVES * TS_ITEMS) {  // 128 group counts -> exclusive prefix (two waves)
-      const uint32_t g = qsum[1][tid];
-      uint32_t gi = g;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t x = __shfl_up(gi, o, 64);
-        if (lane >= o) gi += x;
-      }
-      if (lane == 63) wsum[w] = gi;
-      qsum[2][tid] = gi - g;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TS_ITEMS; ++j) {
-      const int e = wbase + j * MI_WAVE + lane;
-      if ((bal[j] >> lane) & 1ull) {
-        const int g = w * TS_ITEMS + j;
-        const uint32_t dest = qsum[2][g] + (g >= 64 ? wsum[0] : 0u) + (uint32_t) __popcll(bal[j] & lt);
-        kbuf[0][dest] = key[j];
-        vbuf[0][dest] = vbuf[1][e];
-      }
-    }
-    __syncthreads();
+    base += total;
   }
-  const int cur = ts_lds_sort(L, m, passes, 0);
-  if (passes == 0) __syncthreads();  // keys of zero bits: the fill must still be visible
-  m_out = m;
-  out_base_out = out_base;
-  return cur;
+  return false;
 }
 
 // Part `part` of `parts` of table `t` is sorted by the calling workgroup (all TS_THREADS threads
@@ -274,47 +219,160 @@ __device__ __forceinline__ void table_sort_body(int t, int part, int parts, cons
   __shared__ TsLds L;
   auto& kbuf = L.kbuf;
   auto& vbuf = L.vbuf;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  TS_MARK(0);
   const int64_t base_row = toffs[t];
   const uint32_t rows = (uint32_t) (toffs[t + 1] - base_row);
   int bits = 0;
   for (uint32_t v = rows; v; v >>= 1) ++bits;  // values 0..rows
-  // local key: the id, or `rows` (one past the largest) for a padding / out-of-range entry;
-  // image 0 when the workgroup sorts the whole table, image 1 (scratch) when it first selects
-  const int first = parts > 1 ? 1 : 0;
-  // all of a thread's ids are requested before the first is used: the loads carry no branch around them
-  // (entries past n re-read entry 0; where control flow joins behind a load the compiler waits for every
+  if (parts > 1 && n < MI_WAVE) {  // too few entries to sample: one workgroup sorts them all
+    if (part > 0) return;
+    parts = 1;
+  }
+  // entry e of the table is its e-th (sample, position-in-bag) pair; equal rows keep that order.  Wave w holds
+  // e = w*512 + k*64 + lane.  Local key: the id, or `rows` (one past the largest) for a padding / out-of-range
+  // entry.  All of a thread's ids are requested before the first is used: the loads carry no branch around
+  // them (entries past n re-read entry 0; where control flow joins behind a load the compiler waits for every
   // outstanding load, which made these eight loads eight dependent round trips)
-  int64_t idv[TS_ITEMS];
-  int pv[TS_ITEMS];
+  // e / bag_len without the integer division (some 25 instructions, nine times per thread): e and bag_len are
+  // at most TS_MAX, so (e + 0.5) / bag_len in single precision is off by far less than the 0.5 / bag_len that
+  // separates it from the next integer
+  const float inv_len = __builtin_amdgcn_rcpf((float) bag_len);
+  auto place = [&](int e) {  // where entry e's id lies in a sample-major id array
+    if (bag_len == 1) return e * T + t;
+    const int b = (int) (((float) e + 0.5f) * inv_len);
+    return (b * T + t) * bag_len + (e - b * bag_len);
+  };
+  int64_t idv[TS_ITEMS], sid;
+  int pv[TS_ITEMS], es[TS_ITEMS];
+  const int se = lane * (n >> 6);  // the 64 samples (parts > 1: n >= 64)
 #pragma unroll
   for (int k = 0; k < TS_ITEMS; ++k) {
-    const int e = k * TS_THREADS + tid;
-    const int es = e < n ? e : 0;
-    const int b = es / bag_len;
-    pv[k] = (b * T + t) * bag_len + (es - b * bag_len);
+    const int e = (w * TS_ITEMS + k) * MI_WAVE + lane;
+    es[k] = e < n ? e : 0;
+    pv[k] = place(es[k]);
+  }
+  if (ids_tm) {
     // table-major ids (bag_len 1): the table's ids are one contiguous run, a full-line load per wave
     // instead of one line per id
-    idv[k] = mi_ld_id<IDX>(indices, ids_tm ? (int64_t) t * n + es : (int64_t) pv[k]);
-  }
+    const int64_t first = (int64_t) t * n;
 #pragma unroll
-  for (int k = 0; k < TS_ITEMS; ++k) {
-    const int e = k * TS_THREADS + tid;
-    if (e < n) {
-      kbuf[first][e] = (idv[k] >= 0 && idv[k] < (int64_t) rows) ? (uint32_t) idv[k] : rows;
-      vbuf[first][e] = (uint32_t) pv[k];
+    for (int k = 0; k < TS_ITEMS; ++k) idv[k] = mi_ld_id<IDX>(indices, first + es[k]);
+    sid = mi_ld_id<IDX>(indices, first + se);
+  } else {
+#pragma unroll
+    for (int k = 0; k < TS_ITEMS; ++k) idv[k] = mi_ld_id<IDX>(indices, (int64_t) pv[k]);
+    sid = mi_ld_id<IDX>(indices, (int64_t) place(se));
+  }
+  uint32_t key[TS_ITEMS];
+#pragma unroll
+  for (int k = 0; k < TS_ITEMS; ++k) key[k] = (idv[k] >= 0 && idv[k] < (int64_t) rows) ? (uint32_t) idv[k] : rows;
+  int m = n, out_base = 0;  // entries this workgroup sorts, and where its output starts in the table's block
+  uint32_t key_lo = 0;      // subtracted from the keys it sorts
+  TS_MARK(1);
+  if (parts == 1) {
+#pragma unroll
+    for (int k = 0; k < TS_ITEMS; ++k) {
+      const int e = (w * TS_ITEMS + k) * MI_WAVE + lane;
+      if (e < n) {
+        kbuf[0][e] = key[k];
+        vbuf[0][e] = (uint32_t) pv[k];
+      }
+    }
+  } else {
+    // rank the samples by (key, lane); keys of more than 26 bits lose their low bits here, which only moves
+    // the cuts a little: any cut every workgroup of the table agrees on is a valid one.  Every wave holds all
+    // 64 samples; wave w counts how many of samples 4w..4w+3 precede each, and after one barrier every wave
+    // adds up the sixteen partial ranks for itself.
+    const uint32_t skey = (sid >= 0 && sid < (int64_t) rows) ? (uint32_t) sid : rows;
+    const uint32_t s32 = ((skey >> (bits > 26 ? bits - 26 : 0)) << 6) | (uint32_t) lane;
+    {
+      uint32_t pr = 0;
+#pragma unroll
+      for (int j = 0; j < MI_WAVE / TS_WAVES; ++j)
+        pr += (uint32_t) __builtin_amdgcn_readlane((int) s32, w * (MI_WAVE / TS_WAVES) + j) < s32 ? 1u : 0u;
+      L.cnt[w][lane] = pr;
+    }
+    TS_MARK(11);
+    __syncthreads();
+    TS_MARK(12);
+    uint32_t rank = 0;
+#pragma unroll
+    for (int i = 0; i < TS_WAVES; ++i) rank += L.cnt[i][lane];
+    unsigned long long lo = 0ull, hi = ~0ull;
+    {
+      const unsigned long long sc = ((unsigned long long) skey << 13) | (unsigned long long) se;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int q = part + s;
+        if (q > 0 && q < parts) {
+          const unsigned long long hit = __ballot(rank == (uint32_t) (q * MI_WAVE / parts));  // one lane: ranks are a permutation
+          const int src = __ffsll((long long) hit) - 1;
+          const unsigned long long c =
+              ((unsigned long long) (uint32_t) __builtin_amdgcn_readlane((int) (sc >> 32), src) << 32) |
+              (unsigned long long) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) sc, src);
+          if (s == 0) lo = c; else hi = c;
+        }
+      }
+    }
+    TS_MARK(2);
+    // stable selection: entry e of the table keeps its place among the selected ones.  The masks are kept as
+    // the 64-bit scalars the compares produce, so combining and counting them costs no vector instruction.
+    unsigned long long bal[TS_ITEMS];
+    uint32_t sel_before[TS_ITEMS];
+    uint32_t nsel = 0, nbelow = 0;
+#pragma unroll
+    for (int k = 0; k < TS_ITEMS; ++k) {
+      const int e = (w * TS_ITEMS + k) * MI_WAVE + lane;
+      const unsigned long long c = ((unsigned long long) key[k] << 13) | (unsigned long long) e;
+      const unsigned long long valid = __builtin_amdgcn_ballot_w64(e < n), ge = __builtin_amdgcn_ballot_w64(c >= lo),
+                               lt = __builtin_amdgcn_ballot_w64(c < hi);
+      bal[k] = valid & ge & lt;
+      sel_before[k] = nsel;
+      nsel += (uint32_t) __popcll(bal[k]);
+      nbelow += (uint32_t) __popcll(valid & ~ge);
+    }
+    if (lane == 0) {
+      L.wsel[w][0] = nsel;
+      L.wsel[w][1] = nbelow;
+    }
+    __syncthreads();
+    // lane i < 16 takes wave i's two counts; a wave scan gives every wave its first place, and the totals
+    const uint32_t a_sel = lane < TS_WAVES ? L.wsel[lane][0] : 0u, a_below = lane < TS_WAVES ? L.wsel[lane][1] : 0u;
+    const uint32_t i_sel = ts_wave_scan(a_sel), i_below = ts_wave_scan(a_below);
+    const uint32_t wave_first = (uint32_t) __builtin_amdgcn_readlane((int) (i_sel - a_sel), w);
+    m = __builtin_amdgcn_readlane((int) i_sel, MI_WAVE - 1);
+    out_base = __builtin_amdgcn_readlane((int) i_below, MI_WAVE - 1);
+    // the part's keys lie between the keys of its two cuts: sorting key - key_lo needs fewer bits (none at all
+    // where the part is a run of one key)
+    key_lo = (uint32_t) (lo >> 13);
+    const uint32_t span = (part == parts - 1 ? rows : (uint32_t) (hi >> 13)) - key_lo;
+    bits = 0;
+    for (uint32_t v = span; v; v >>= 1) ++bits;
+#pragma unroll
+    for (int k = 0; k < TS_ITEMS; ++k) {
+      if (__builtin_amdgcn_inverse_ballot_w64(bal[k])) {
+        const uint32_t dest = __builtin_amdgcn_mbcnt_hi((uint32_t) (bal[k] >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((uint32_t) bal[k], wave_first + sel_before[k]));
+        kbuf[0][dest] = key[k] - key_lo;
+        vbuf[0][dest] = (uint32_t) pv[k];
+      }
     }
   }
-  int m, out_base;  // entries this workgroup sorts, and where its output starts in the table's block
-  const int cur = ts_sort_part(L, n, part, parts, bits, m, out_base);
+  TS_MARK(3);
+  const int cur = ts_lds_sort_bits(L, m, bits, 0);  // (its first barrier makes the fill visible, also for keys of zero bits)
   const size_t out = (size_t) t * n + out_base;
 #pragma unroll
   for (int k = 0; k < TS_ITEMS; ++k) {
     const int e = k * TS_THREADS + tid;
     if (e < m) {
-      const uint32_t lk = kbuf[cur][e];
+      const uint32_t lk = kbuf[cur][e] + key_lo;
       sorted_rows[out + e] = lk < rows ? (uint32_t) (base_row + lk) : sentinel;
       perm[out + e] = vbuf[cur][e];
     }
   }
+  TS_MARK(8);
+#ifdef TS_TRACE
+  if (threadIdx.x == 0) { ts_trace_buf[blockIdx.x * 16 + 9] = (unsigned long long) bits; ts_trace_buf[blockIdx.x * 16 + 10] = (unsigned long long) m; }
+#endif
 }
