@@ -644,16 +644,25 @@ __device__ __forceinline__ void block_run(const PlanDev& pl, const Src& src, con
 // the update.  Two dependent memory round trips per wave however the 64 entries split into runs,
 // and no per-round search for the k-th head.  The one run that may continue past the wave's last
 // entry is left to wave_pending as before.
-// cs: 64 * (LANES*VEC + 4) floats, ss: 64 floats, hp: 65 ints - this wave's own.
+// cs: (64 + 64/LANES) * (LANES*VEC + 4) floats, ss: 64 + 64/LANES floats, hp: 65 ints - this wave's own.
 template <int VEC, int LANES, class Src, class Upd>
 __device__ __forceinline__ void short_wave_lds(const PlanDev& pl, const Src& src, const Upd& upd, int base,
-                                               uint32_t key, int perm_reg, unsigned long long hm,
-                                               uint32_t after_wave, uint32_t sentinel, float* __restrict__ cs,
+                                               uint32_t key, int perm_reg, uint32_t key2, int perm2,
+                                               unsigned long long hm, uint32_t sentinel, float* __restrict__ cs,
                                                float* __restrict__ ss, int* __restrict__ hp) {
   constexpr int G = 64 / LANES, R = LANES, STR = LANES * VEC + 4;
   const int lane = threadIdx.x & 63, g = lane / LANES, c = lane - g * LANES;
   const int nheads = __popcll(hm);
   if (nheads == 0) return;  // all 64 entries continue a run that started earlier: its opener's job (uniform)
+  // The wave's last run may go on in the following entries (key2 / perm2: the next 64 rows and permutation
+  // entries, requested with the wave's own; a row past the end of the array reads as the sentinel).  Up to G
+  // more entries are taken along - one more source per lane group, in the same round trip as the others -
+  // so the run costs its owner nothing extra; only a longer continuation is left to wave_pending, whose
+  // search for the end and second round of loads start when everything else is done.
+  const uint32_t last_row = (uint32_t) __shfl((int) key, 63, 64);
+  const unsigned long long differs = __ballot(key2 != last_row);
+  const int ext_all = last_row == sentinel ? 0 : (differs ? __ffsll((long long) differs) - 1 : 64);  // uniform
+  const int ext = ext_all <= G ? ext_all : 0;
   const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
   if ((hm >> lane) & 1ull) hp[__popcll(hm & lt)] = lane;
   if (lane == 0) hp[nheads] = 64;
@@ -675,11 +684,15 @@ __device__ __forceinline__ void short_wave_lds(const PlanDev& pl, const Src& src
     len[q] = in ? hp[k + 1] - pos[q] : 0;
     row[q] = (uint32_t) __shfl((int) key, pos[q], 64);
     have[q] = in && row[q] != sentinel;
-    if (have[q] && k == nheads - 1 && base + 64 < pl.n && after_wave == row[q]) {  // continues in the next wave
-      have[q] = false;
-      pending = (c == 0);
-      pend_beg = base + pos[q];
-      pend_row = row[q];
+    if (have[q] && k == nheads - 1) {  // the wave's last run
+      if (ext_all > G) {               // goes on for more entries than are taken along
+        have[q] = false;
+        pending = (c == 0);
+        pend_beg = base + pos[q];
+        pend_row = row[q];
+      } else {
+        len[q] += ext;  // its continuation is staged behind the wave's own 64 entries
+      }
     }
     // unconditional (a branch around a load makes the compiler wait for all outstanding loads where the
     // paths join): a slot without a run reads row 0, which exists
@@ -690,6 +703,15 @@ __device__ __forceinline__ void short_wave_lds(const PlanDev& pl, const Src& src
   for (int r = 0; r < R; ++r) {
     const int p = __shfl(perm_reg, r * G + g, 64);
     src.template load<VEC>(pl, p, c, v[r], sv[r]);
+  }
+  if (ext > 0) {  // uniform; joins where every load above is awaited anyway
+    float v2[VEC], s2;
+    src.template load<VEC>(pl, __shfl(perm2, g < ext ? g : 0, 64), c, v2, s2);
+    if (g < ext) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) cs[(64 + g) * STR + c * VEC + k] = v2[k];
+      if (c == 0) ss[64 + g] = s2;
+    }
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -749,8 +771,8 @@ static_assert(FM_DENSE_THREADS == UBLOCK, "the dense side runs in workgroups of 
 // is compiled, which keeps the kernel under 128 vector registers - four waves per SIMD instead of
 // three), 0 for any other width (lanes is then read from the argument).
 template <int VEC, bool SPLIT, int LP, class Src, class Upd, class Extra>
-__global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src, Upd upd, int lanes_arg, int groups,
-                                                           int long_blocks, Extra extra, int epw_arg) {
+__device__ __forceinline__ void seg_sorted_body(PlanDev pl, Src src, Upd upd, int lanes_arg, int groups,
+                                                int long_blocks, Extra extra, int epw_arg) {
   const int lanes = LP > 0 ? LP : lanes_arg;
   // entries per wave: 64, or fewer (wide rows, few entries) so that a small batch still spreads over
   // the chip - a wave of 64 entries with two lane groups is 8 or more rounds of dependent loads
@@ -935,6 +957,11 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
   // the wave's permutation entries, requested with its rows (one coalesced load): a run that closes
   // inside the wave gets its entries by shuffle instead of a dependent load per run
   const int perm_reg = pl.perm[mine ? i : base];
+  // narrow rows: also the next 64 rows and permutation entries, for a last run that goes on past the wave
+  const bool mine2 = LP > 0 && i + 64 < pl.n;
+  const uint32_t key2r = LP > 0 ? keys[mine2 ? i + 64 : base] : 0u;
+  const int perm2 = LP > 0 ? pl.perm[mine2 ? i + 64 : base] : 0;
+  const uint32_t key2 = mine2 ? key2r : sentinel;
   uint32_t edge = sentinel;  // lane 0: the row before the wave's first; lane epw-1: the row after its last
   if (lane == 0 && base > 0) edge = keys[base - 1];
   if (lane == epw - 1 && base + epw < pl.n) edge = keys[base + epw];
@@ -949,11 +976,12 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
   const unsigned long long hm = __ballot(head) & wmask;
   const int nheads = __popcll(hm);
   if constexpr (LP > 0) {
-    __shared__ float lds_cs[UBLOCK / 64][64 * (LP * VEC + 4)];
-    __shared__ float lds_ss[UBLOCK / 64][64];
+    __shared__ float lds_cs[UBLOCK / 64][(64 + 64 / LP) * (LP * VEC + 4)];
+    __shared__ float lds_ss[UBLOCK / 64][64 + 64 / LP];
     __shared__ int lds_hp[UBLOCK / 64][65];
     const int w = threadIdx.x >> 6;
-    short_wave_lds<VEC, LP>(pl, src, upd, base, key, perm_reg, hm, after_wave, sentinel, lds_cs[w], lds_ss[w], lds_hp[w]);
+    short_wave_lds<VEC, LP>(pl, src, upd, base, key, perm_reg, key2, perm2, hm, sentinel, lds_cs[w], lds_ss[w],
+                            lds_hp[w]);
     return;
   }
   const int G = 64 / lanes, g = lane / lanes, c = lane - g * lanes;
@@ -1016,6 +1044,29 @@ __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src,
     }
     wave_pending<VEC>(pl, src, upd, lanes, pending, base + pos, open ? -1 : base + endpos, row, base + pos, false);
   }
+}
+
+#ifdef SEG_TRACE
+static __device__ unsigned long long seg_trace_buf[4096 * 2];
+extern "C" int mi_debug_seg_trace(unsigned long long* host_out, int n) {
+  return (int) hipMemcpyFromSymbol(host_out, HIP_SYMBOL(seg_trace_buf), (size_t) n * 8);
+}
+#endif
+
+template <int VEC, bool SPLIT, int LP, class Src, class Upd, class Extra>
+__global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src, Upd upd, int lanes_arg, int groups,
+                                                           int long_blocks, Extra extra, int epw_arg) {
+#ifdef SEG_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    seg_trace_buf[blockIdx.x * 2] = wall_clock64();
+    seg_trace_buf[blockIdx.x * 2 + 1] = 0;
+  }
+#endif
+  seg_sorted_body<VEC, SPLIT, LP>(pl, src, upd, lanes_arg, groups, long_blocks, extra, epw_arg);
+#ifdef SEG_TRACE
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) atomicMax(&seg_trace_buf[blockIdx.x * 2 + 1], (unsigned long long) wall_clock64());
+#endif
 }
 
 // Queued runs (longer than WAVE_MAX, or longer than 4 when lane groups straddle waves): one
