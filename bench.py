@@ -45,6 +45,7 @@ def parse_args():
                     help='table optimizer (default adam_tf, the form of the reference\'s tf.train.AdamOptimizer)')
     ap.add_argument('--dist', default='uniform', choices=['uniform', 'zipf'])
     ap.add_argument('--idx-bits', type=int, default=64, choices=[32, 64])
+    ap.add_argument('--seed', type=int, default=0, help='fm workload: seed of the synthetic batches (rank r draws from 1000 + seed + r)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=50)
     ap.add_argument('--stage-reps', type=int, default=50)
@@ -922,7 +923,7 @@ def main():
     else:
         from recommendation_amd.sharded import ShardedFactorizationMachine
         model = ShardedFactorizationMachine(rows, args.dim, 13, device=dev, opt=args.opt, lr=1e-3, seed=0)
-    batches = gen_batches(8, B, rows, 13, args.dist, args.idx_bits, dev, seed=1000 + rank)
+    batches = gen_batches(8, B, rows, 13, args.dist, args.idx_bits, dev, seed=1000 + args.seed + rank)
 
     def barrier():
         if sharded:
@@ -967,7 +968,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'fm_criteo_%dx%d_b%d' % (len(rows), args.dim, B), 'global_batch': B * world,
                        'tables': len(rows), 'total_rows': int(sum(rows)), 'dim': args.dim, 'n_dense': 13,
-                       'id_bits': args.idx_bits, 'ids': args.dist,
+                       'id_bits': args.idx_bits, 'ids': args.dist, 'seed': args.seed,
                        'id_layout': 'field-major [T][B]' if tms else 'sample-major [B][T]', 'optimizer': args.opt,
                        'launch': 'hip graph replay' if use_graph else 'eager',
                        'sort': ('next batch\'s ids sorted on a side stream beside this step' if prefetch_sort
