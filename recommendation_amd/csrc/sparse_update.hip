@@ -1024,8 +1024,8 @@ __device__ __forceinline__ void seg_sorted_body(PlanDev pl, Src src, Upd upd, in
       return;
     }
   }
-  for (int r = 0; r * G < nheads; ++r) {  // uniform over the wave
-    const int k = r * G + g;
+  // One round of the general path: lane group g takes head k (if there is one) whatever its run looks like.
+  auto one_head = [&](int k) {
     const int pos = k < nheads ? kth_set_bit(hm, k) : 0;
     const unsigned long long later = (pos < 63) ? (hm & ~((2ull << pos) - 1ull)) : 0ull;  // heads after pos
     const int endpos = later ? __ffsll((long long) later) - 1 : epw;
@@ -1043,7 +1043,77 @@ __device__ __forceinline__ void seg_sorted_body(PlanDev pl, Src src, Upd upd, in
       else pending = (c == 0);
     }
     wave_pending<VEC>(pl, src, upd, lanes, pending, base + pos, open ? -1 : base + endpos, row, base + pos, false);
+  };
+  if constexpr (Src::kBatchSingles && Upd::kBatchSingles > 0) {
+    // Waves that mix one-entry runs with a few longer ones (a third of the waves when the tables are ~70 x the
+    // batch): a lane group still takes BT heads per round - row states and first gradient sources of all BT
+    // requested together, the second sources only if some run of the round has two entries - as long as every
+    // run of the round closes inside the wave with at most two entries and none is padding.  A round that holds
+    // anything else goes head by head as before.  Sums are formed as group_run4_pre forms them: same bits.
+    constexpr int BT = Upd::kBatchSingles;
+    if (lanes >= BT) {
+      for (int r0 = 0; r0 * G < nheads; r0 += BT) {  // uniform over the wave
+        int pos[BT], len[BT];
+        uint32_t row[BT];
+        bool have[BT];
+        bool simple = true, two = false;
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+          const int k = (r0 + u) * G + g;
+          const bool in = k < nheads;
+          pos[u] = in ? kth_set_bit(hm, k) : 0;
+          const unsigned long long later = (pos[u] < 63) ? (hm & ~((2ull << pos[u]) - 1ull)) : 0ull;
+          const int endpos = later ? __ffsll((long long) later) - 1 : epw;
+          row[u] = (uint32_t) __shfl((int) key, pos[u], 64);
+          have[u] = in && row[u] != sentinel;
+          const bool open = have[u] && !later && base + epw < pl.n && after_wave == row[u];
+          len[u] = endpos - pos[u];
+          simple = simple && (!in || (have[u] && !open && len[u] <= 2));
+          two = two || (have[u] && len[u] == 2);
+        }
+        if (__ballot(!simple) == 0ull) {  // uniform
+          typename Upd::template Regs<VEC> regs[BT];
+          int p0[BT], p1[BT];
+#pragma unroll
+          for (int u = 0; u < BT; ++u) {
+            p0[u] = __shfl(perm_reg, pos[u], 64);
+            p1[u] = __shfl(perm_reg, pos[u] + 1 < epw ? pos[u] + 1 : pos[u], 64);
+            upd.template load<VEC>(have[u] ? (int64_t) row[u] : 0, c, regs[u]);  // no branch around the load
+          }
+          float v[BT][VEC], sc[BT];
+#pragma unroll
+          for (int u = 0; u < BT; ++u) src.template load<VEC>(pl, p0[u], c, v[u], sc[u]);
+#pragma unroll
+          for (int u = 0; u < BT; ++u) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[u][k] = 0.f + v[u][k];
+            sc[u] = 0.f + sc[u];
+          }
+          if (__ballot(two) != 0ull) {  // uniform; everything requested so far is awaited below anyway
+            float v2[BT][VEC], s2[BT];
+#pragma unroll
+            for (int u = 0; u < BT; ++u) src.template load<VEC>(pl, p1[u], c, v2[u], s2[u]);
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+              if (len[u] == 2) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v[u][k] += v2[u][k];
+                sc[u] += s2[u];
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < BT; ++u) {
+            if (have[u]) upd.template finish<VEC>((int64_t) row[u], c, lanes, regs[u], v[u], sc[u]);
+          }
+        } else {
+          for (int u = 0; u < BT && (r0 + u) * G < nheads; ++u) one_head((r0 + u) * G + g);  // uniform bounds
+        }
+      }
+      return;
+    }
   }
+  for (int r = 0; r * G < nheads; ++r) one_head(r * G + g);  // uniform over the wave
 }
 
 #ifdef SEG_TRACE
