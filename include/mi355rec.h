@@ -165,7 +165,21 @@ typedef struct mi_bwd_plan {
   const void* indices;
   int idx_bits;
   const int64_t* table_offsets;
+  /* optional, filled by mi_embag_bag_info (either may be NULL):
+   * bag_scale[n_bags]: 1 / (count of valid ids of the bag), 1 for a bag with fewer than two - what an entry of a
+   *   mean-pooled bag multiplies its bag's gradient by; without it every entry recounts its bag's ids;
+   * entry_bag[n_entries]: the bag of each position of `indices` for CSR bags; without it every entry finds its
+   *   bag by binary search in `offsets`. */
+  const float* bag_scale;
+  const int32_t* entry_bag;
 } mi_bwd_plan;
+
+/* Per-bag facts the apply calls would otherwise recompute per ENTRY (see mi_bwd_plan): one wave per bag counts the
+ * bag's valid ids (0 <= id < rows of its table) into bag_scale and, for CSR bags, writes entry_bag.  Either output
+ * may be NULL.  No reference counterpart (the reference's bags are fixed-width and sum-pooled, r_model.py:68-80). */
+int mi_embag_bag_info(const int64_t* table_offsets, int T, const void* indices, int idx_bits,
+                      const int64_t* offsets, int bag_len, int64_t n_bags, float* bag_scale,
+                      int32_t* entry_bag, void* stream);
 
 /* Dense gradient dW[total_rows][dim] (zero on untouched rows): what TensorFlow's MatMul
  * gradient X^T dY yields for a one-hot X (model_trainer.py:157-158). */

@@ -31,6 +31,7 @@ class BwdPlan(Structure):
         ('n_entries', c_int64), ('n_bags', c_int64), ('total_rows', c_int64), ('offsets', c_void_p),
         ('bag_len', c_int), ('T', c_int), ('pool_mode', c_int), ('long_list', c_void_p),
         ('indices', c_void_p), ('idx_bits', c_int), ('table_offsets', c_void_p),
+        ('bag_scale', c_void_p), ('entry_bag', c_void_p),
     ]
 
 
@@ -55,6 +56,7 @@ _SIGNATURES = {
                              c_int64, P, P]),
     'mi_onehot_dense': (c_int, [P, c_int, c_int, c_int64, c_int, c_int, P, P, P]),
     'mi_validate_ids': (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P, P]),
+    'mi_embag_bag_info': (c_int, [P, c_int, P, c_int, P, c_int, c_int64, P, P, P]),
     'mi_embag_bwd_workspace_bytes': (c_size_t, [c_int64]),
     'mi_embag_bwd_prepare': (c_int, [P, c_int, c_int64, P, c_int, P, c_int, c_int64, c_int64, P, P, P, P, P,
                                      P, c_size_t, P]),

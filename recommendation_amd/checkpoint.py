@@ -6,16 +6,23 @@ The reference saves through tf.train.MonitoredTrainingSession(checkpoint_dir=...
   <variable>/Adam, <variable>/Adam_1                                   (AdamOptimizer's m and v slots)
   beta1_power, beta2_power                                             (its fp32 schedule variables)
   global_step
-No checkpoint ships with the reference and TensorFlow is not available to write one, so the
-container here is a plain ``.npz`` whose KEYS are exactly those names ('/' kept): converting a
-bundle to it is one tf.train.load_checkpoint loop on a machine that has TensorFlow.  The first-layer
-kernels keep the reference's shapes ([256, 8] for the concatenated recommend/click towers), so
-nothing has to be split or merged.
+Two containers, both keyed by exactly those names ('/' kept):
+* ``fmt='bundle'``: TensorFlow's own on-disk form, ``model.ckpt-<step>.index`` +
+  ``model.ckpt-<step>.data-00000-of-00001`` (tf_bundle.py restates the format), which is what a
+  reference-trained checkpoint directory holds and what ``load`` / ``latest`` look for first;
+* ``fmt='npz'`` (the default for ``save``): a plain ``.npz``.
+No checkpoint ships with the reference and TensorFlow is not available here, so the bundle path has been
+exercised only on files this module wrote (checksums, known answers and round trips pin the format
+code).  The first-layer kernels keep the reference's shapes ([256, 8] for the concatenated recommend /
+click towers); ``split_first_layer`` / ``merge_first_layer`` convert between that and the two embedding
+tables R and K the gather formulation speaks of (r_model.py:31-40).
 """
 import os
 
 import numpy as np
 import torch
+
+from . import tf_bundle
 
 
 def variables_of(model, optimizer=None):
@@ -34,30 +41,62 @@ def variables_of(model, optimizer=None):
     return out
 
 
-def save(checkpoint_dir, model, optimizer=None, step=None):
-    """Write ``model.ckpt-<step>.npz`` under checkpoint_dir and point ``checkpoint`` at it (the file
+def split_first_layer(kernel, colour_count):
+    """``dense_2/kernel`` or ``dense_5/kernel`` [2*colour_count, 8] -> (R, K): the rows the n-hot recommend
+    input selects and the rows the one-hot click input selects (concat order of r_model.py:36-38)."""
+    if kernel.shape[0] != 2 * colour_count:
+        raise ValueError("kernel has %d rows, expected %d" % (kernel.shape[0], 2 * colour_count))
+    return kernel[:colour_count], kernel[colour_count:]
+
+
+def merge_first_layer(R, K):
+    return np.concatenate([R, K], axis=0)
+
+
+def save(checkpoint_dir, model, optimizer=None, step=None, fmt='npz'):
+    """Write ``model.ckpt-<step>`` under checkpoint_dir - as ``.npz`` or, with ``fmt='bundle'``, as a
+    TensorFlow bundle (.index + .data-00000-of-00001) - and point ``checkpoint`` at it (the file
     TensorFlow keeps there, model_trainer.py:55-63 rewrites the same file)."""
     os.makedirs(checkpoint_dir, exist_ok=True)
     values = variables_of(model, optimizer)
     step = int(values['global_step']) if step is None else int(step)
     name = 'model.ckpt-%d' % step
-    np.savez(os.path.join(checkpoint_dir, name + '.npz'), **values)
+    if fmt == 'bundle':
+        path = tf_bundle.write_bundle(os.path.join(checkpoint_dir, name), {k: np.asarray(v) for k, v in values.items()})
+    elif fmt == 'npz':
+        path = os.path.join(checkpoint_dir, name + '.npz')
+        np.savez(path, **values)
+    else:
+        raise ValueError("fmt must be 'npz' or 'bundle'")
     with open(os.path.join(checkpoint_dir, 'checkpoint'), 'w') as f:
         f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (name, name))
-    return os.path.join(checkpoint_dir, name + '.npz')
+    return path
 
 
 def latest(checkpoint_dir):
-    """Path of the newest checkpoint named by the ``checkpoint`` file, or None."""
+    """Path of the newest checkpoint named by the ``checkpoint`` file, or None: the bundle prefix when
+    ``<name>.index`` exists (what tf.train.latest_checkpoint returns), else ``<name>.npz``."""
     index = os.path.join(checkpoint_dir, 'checkpoint')
     if not os.path.exists(index):
         return None
     for line in open(index):
         if line.startswith('model_checkpoint_path:'):
             name = line.split(':', 1)[1].strip().strip('"')
-            path = os.path.join(checkpoint_dir, os.path.basename(name) + '.npz')
-            return path if os.path.exists(path) else None
+            base = os.path.join(checkpoint_dir, os.path.basename(name))
+            if os.path.exists(base + '.index'):
+                return base
+            return base + '.npz' if os.path.exists(base + '.npz') else None
     return None
+
+
+def read_values(path):
+    """name -> array of a checkpoint: a bundle prefix (or its .index file) or an .npz."""
+    if path.endswith('.index'):
+        path = path[:-len('.index')]
+    if os.path.exists(path + '.index'):
+        return tf_bundle.read_bundle(path)
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
 
 
 def load(path_or_dir, model, optimizer=None):
@@ -66,8 +105,7 @@ def load(path_or_dir, model, optimizer=None):
     path = latest(path_or_dir) if os.path.isdir(path_or_dir) else path_or_dir
     if path is None:
         raise FileNotFoundError("no checkpoint under %s" % path_or_dir)
-    with np.load(path, allow_pickle=False) as z:
-        values = {k: z[k] for k in z.files}
+    values = read_values(path)
     slots = ('/Adam', '/Adam_1')
     model.load_variables({k: v for k, v in values.items()
                           if not k.endswith(slots) and k not in ('beta1_power', 'beta2_power', 'global_step')})

@@ -282,6 +282,37 @@ __global__ __launch_bounds__(256) void validate_kernel(const int64_t* __restrict
   if (bad) atomicOr(err, bad);
 }
 
+// One wave per bag: lanes stride over the bag's ids (coalesced), count the valid ones with a wave reduction and
+// note the bag against each position.
+template <typename IDX>
+__global__ __launch_bounds__(256) void bag_info_kernel(const int64_t* __restrict__ toffs, int T,
+                                                      const void* __restrict__ indices,
+                                                      const int64_t* __restrict__ offsets, int bag_len, int n_bags,
+                                                      float* __restrict__ bag_scale, int32_t* __restrict__ entry_bag) {
+  const int lane = threadIdx.x & 63;
+  const int bag = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bag >= n_bags) return;  // uniform over the wave
+  const int t = bag % T;
+  const int64_t rows = toffs[t + 1] - toffs[t];
+  int64_t beg, end;
+  if (offsets) {
+    beg = offsets[bag];
+    end = offsets[bag + 1];
+  } else {
+    beg = (int64_t) bag * bag_len;
+    end = beg + bag_len;
+  }
+  int cnt = 0;
+  for (int64_t j = beg + lane; j < end; j += 64) {
+    const int64_t id = mi_ld_id<IDX>(indices, j);
+    cnt += (id >= 0 && id < rows) ? 1 : 0;
+    if (entry_bag) entry_bag[j] = bag;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if (lane == 0 && bag_scale) bag_scale[bag] = cnt > 1 ? 1.0f / (float) cnt : 1.0f;
+}
+
 template <typename IDX>
 int launch_fwd(const float* weights, const int64_t* toffs, int T, int dim, const void* indices,
                const int64_t* offsets, int bag_len, int n_bags, int pool_mode, int flags, const float* bias,
@@ -349,6 +380,27 @@ extern "C" int mi_embag_fwd(const float* weights, const int64_t* table_offsets, 
                                pool_mode, check_flags, bias, out, out_dtype, out_ld, err, s);
   return launch_fwd<int64_t>(weights, table_offsets, T, dim, indices, offsets, bag_len, (int) n_bags, pool_mode,
                              check_flags, bias, out, out_dtype, out_ld, err, s);
+}
+
+extern "C" int mi_embag_bag_info(const int64_t* table_offsets, int T, const void* indices, int idx_bits,
+                                 const int64_t* offsets, int bag_len, int64_t n_bags, float* bag_scale,
+                                 int32_t* entry_bag, void* stream) {
+  if (n_bags == 0 || (!bag_scale && !entry_bag)) return MI_OK;
+  MI_REQUIRE(table_offsets && indices, "mi_embag_bag_info: null pointer");
+  MI_REQUIRE(T >= 1, "mi_embag_bag_info: T=%d", T);
+  MI_REQUIRE(idx_bits == 32 || idx_bits == 64, "mi_embag_bag_info: idx_bits must be 32 or 64");
+  MI_REQUIRE(n_bags > 0 && n_bags < (int64_t) 1 << 31, "mi_embag_bag_info: n_bags out of range");
+  MI_REQUIRE(offsets || bag_len >= 0, "mi_embag_bag_info: bag_len < 0 without offsets");
+  const unsigned grid = (unsigned) mi_cdiv(n_bags, 4);
+  hipStream_t s = (hipStream_t) stream;
+  if (idx_bits == 32)
+    hipLaunchKernelGGL(bag_info_kernel<int32_t>, dim3(grid), dim3(256), 0, s, table_offsets, T, indices, offsets,
+                       bag_len, (int) n_bags, bag_scale, entry_bag);
+  else
+    hipLaunchKernelGGL(bag_info_kernel<int64_t>, dim3(grid), dim3(256), 0, s, table_offsets, T, indices, offsets,
+                       bag_len, (int) n_bags, bag_scale, entry_bag);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
 }
 
 extern "C" int mi_onehot_dense(const void* indices, int idx_bits, int bag_len, int64_t n_bags, int size,

@@ -52,11 +52,14 @@ struct PlanDev {
   const int64_t* offsets;
   const void* indices;
   const int64_t* toffs;
+  const float* bag_scale;     // optional: 1 / count of valid ids per bag (mean pooling)
+  const int32_t* entry_bag;   // optional: bag of each position (CSR bags)
   uint32_t sentinel;
   int n, n_bags, bag_len, T, pool_mode, idx_bits;
 
   __device__ __forceinline__ int bag_of(int p) const {
     if (!offsets) return p / bag_len;
+    if (entry_bag) return entry_bag[p];
     int lo = 0, hi = n_bags;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
@@ -66,6 +69,7 @@ struct PlanDev {
   }
   __device__ __forceinline__ float mean_scale(int bag) const {
     if (pool_mode != MI_POOL_MEAN) return 1.0f;
+    if (bag_scale) return bag_scale[bag];
     const int t = bag % T;
     const int64_t rows = toffs[t + 1] - toffs[t];
     int64_t beg, end;
@@ -1221,9 +1225,10 @@ int check_plan(const mi_bwd_plan* plan, PlanDev* pl, bool need_runs, const char*
              who);
   MI_REQUIRE(plan->offsets || plan->bag_len >= 1, "%s: plan needs offsets or bag_len >= 1", who);
   MI_REQUIRE(plan->pool_mode == MI_POOL_SUM ||
-                 (plan->pool_mode == MI_POOL_MEAN && plan->indices && plan->table_offsets &&
-                  (plan->idx_bits == 32 || plan->idx_bits == 64)),
-             "%s: mean pooling needs indices, idx_bits and table_offsets in the plan", who);
+                 (plan->pool_mode == MI_POOL_MEAN &&
+                  (plan->bag_scale || (plan->indices && plan->table_offsets &&
+                                       (plan->idx_bits == 32 || plan->idx_bits == 64)))),
+             "%s: mean pooling needs bag_scale, or indices, idx_bits and table_offsets, in the plan", who);
   pl->sorted_rows = plan->sorted_rows;
   pl->unique_rows = plan->unique_rows;
   pl->perm = plan->perm;
@@ -1235,6 +1240,8 @@ int check_plan(const mi_bwd_plan* plan, PlanDev* pl, bool need_runs, const char*
   pl->offsets = plan->offsets;
   pl->indices = plan->indices;
   pl->toffs = plan->table_offsets;
+  pl->bag_scale = plan->bag_scale;
+  pl->entry_bag = plan->offsets ? plan->entry_bag : nullptr;
   pl->sentinel = (uint32_t) plan->total_rows;
   pl->n = (int) plan->n_entries;
   pl->n_bags = (int) plan->n_bags;

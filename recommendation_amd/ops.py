@@ -176,6 +176,11 @@ class SortedPlan(object):
             workspace = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
         self.workspace = workspace
         self.pool_mode = pool_mode
+        # per-bag facts the apply kernels would otherwise recompute per entry: the mean-pooling scale
+        # and, for CSR bags, the bag of each position
+        self.bag_scale = (torch.empty(max(n_bags, 1), dtype=torch.float32, device=dev)
+                          if pool_mode == MI_POOL_MEAN else None)
+        self.entry_bag = torch.empty(max(n, 1), dtype=torch.int32, device=dev) if offsets is not None else None
         self._bind()
         self.prepare()
 
@@ -192,6 +197,9 @@ class SortedPlan(object):
                   _idx_bits(self.indices), _p(self.offsets), self.bag_len, self.n_bags, self.n_entries,
                   _p(self.sorted_rows), _p(self.perm), _p(self.unique_rows), _p(self.seg_offsets), _p(self.counts),
                   _p(self.workspace), self.workspace.numel(), _stream())
+        if self.bag_scale is not None or self.entry_bag is not None:
+            _lib.call('mi_embag_bag_info', _p(self.toffs), self.T, _p(self.indices), _idx_bits(self.indices),
+                      _p(self.offsets), self.bag_len, self.n_bags, _p(self.bag_scale), _p(self.entry_bag), _stream())
         return self
 
     def prepare_prefix(self, n):
@@ -217,7 +225,9 @@ class SortedPlan(object):
             total_rows=self.total_rows,
             offsets=offsets.data_ptr() if offsets is not None else None, bag_len=bag_len, T=T,
             pool_mode=pool_mode, long_list=self.long_list.data_ptr(), indices=self.indices.data_ptr(),
-            idx_bits=_idx_bits(self.indices), table_offsets=toffs.data_ptr())
+            idx_bits=_idx_bits(self.indices), table_offsets=toffs.data_ptr(),
+            bag_scale=self.bag_scale.data_ptr() if self.bag_scale is not None else None,
+            entry_bag=self.entry_bag.data_ptr() if self.entry_bag is not None else None)
 
     def ref(self):
         return ctypes.byref(self.c)

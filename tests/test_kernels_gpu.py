@@ -241,6 +241,46 @@ def test_dense_grad_equals_onehot_transpose_times_dy(dev, mode, dim):
     assert rel_err(dW.cpu().numpy(), expect) <= RTOL
 
 
+@pytest.mark.parametrize("csr", [False, True])
+def test_bag_info_gives_the_bits_of_per_entry_recounting(dev, csr):
+    """mi_embag_bag_info's per-bag scale and per-position bag (what SortedPlan hands the apply calls) against the
+    numpy count, and the mean-pooled dense gradient with them == without them (each entry recounting its bag's
+    ids and searching the CSR offsets), bit for bit."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(61)
+    dim, T, B = 16, 3, 37
+    rows = [11, 200, 5]
+    toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    if csr:
+        lens = rng.integers(0, 150, size=B * T)
+        lens[5] = 0
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        ids = np.concatenate([rng.integers(-1, rows[i % T], size=l) for i, l in enumerate(lens)]).astype(np.int64)
+        kw = dict(offsets=torch.from_numpy(offsets).to(dev))
+    else:
+        L = 70
+        lens = np.full(B * T, L)
+        offsets = np.arange(B * T + 1, dtype=np.int64) * L
+        ids = np.stack([rng.integers(-1, r, size=(B, L)) for r in rows], axis=1).astype(np.int64)
+        kw = dict(bag_len=L)
+    grad = rng.standard_normal((B, T * dim)).astype(np.float32)
+    plan = ops.SortedPlan(torch.from_numpy(toffs).to(dev), T, int(toffs[-1]), torch.from_numpy(ids).to(dev),
+                          pool_mode=ops.MI_POOL_MEAN, **kw)
+    flat = ids.reshape(-1)
+    cnt = np.array([np.count_nonzero(flat[offsets[i]:offsets[i + 1]] >= 0) for i in range(B * T)])
+    want_scale = np.where(cnt > 1, np.float32(1.0) / np.maximum(cnt, 1).astype(np.float32), np.float32(1.0))
+    assert np.array_equal(plan.bag_scale.cpu().numpy(), want_scale.astype(np.float32))
+    if csr:
+        assert np.array_equal(plan.entry_bag.cpu().numpy()[:len(flat)], np.repeat(np.arange(B * T), lens))
+    g = torch.from_numpy(grad).to(dev)
+    with_info = ops.bwd_dense_grad(plan, g, dim, int(toffs[-1])).clone()
+    plan.bag_scale, plan.entry_bag = None, None
+    plan._bind()
+    without = ops.bwd_dense_grad(plan, g, dim, int(toffs[-1]))
+    assert torch.equal(with_info, without)
+    assert float(with_info.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("opt", ["sgd", "adagrad_rowwise", "adam_tf", "adam_dense_tf"])
 def test_fused_sparse_updates(dev, opt):
     """The fused kernels = (run sums) + (optimizer formula).  The run sums are held to 1e-5

@@ -32,7 +32,10 @@ def test_model_inference_strings_and_threshold(dev):
     assert mi.inference_click(records[0]) == click[:1]             # a single record string (scalar squeeze path)
 
 
-def test_checkpoint_roundtrip_continues_training_bitwise(dev, tmp_path):
+@pytest.mark.parametrize("fmt", ["npz", "bundle"])
+def test_checkpoint_roundtrip_continues_training_bitwise(dev, tmp_path, fmt):
+    """Both containers: the .npz and TensorFlow's bundle (.index + .data-00000-of-00001, what the reference's
+    MonitoredTrainingSession writes, model_trainer.py:165)."""
     from recommendation_amd import checkpoint
     from recommendation_amd.trainer import AdamOptimizer, train_step
     params = oracle_params(7)
@@ -42,9 +45,14 @@ def test_checkpoint_roundtrip_continues_training_bitwise(dev, tmp_path):
                for i in range(6)]
     for b in batches[:3]:
         train_step(a, opt_a, b)
-    path = checkpoint.save(str(tmp_path), a, opt_a)
-    with np.load(path) as z:
-        names = set(z.files)
+    path = checkpoint.save(str(tmp_path), a, opt_a, fmt=fmt)
+    if fmt == 'npz':
+        with np.load(path) as z:
+            names = set(z.files)
+    else:
+        from recommendation_amd import tf_bundle
+        assert checkpoint.latest(str(tmp_path)) == path == str(tmp_path / 'model.ckpt-3')
+        names = set(n for n, _, _ in tf_bundle.list_variables(path))
     # TensorFlow's names: 11 dense layers, their Adam slots, the schedule and the step
     for k in range(11):
         base = 'dense' if k == 0 else 'dense_%d' % k
