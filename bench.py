@@ -749,7 +749,7 @@ def bench_colour(args):
     matrices materialised and multiplied into the first kernels, dense TensorFlow-form Adam."""
     from oracle import colour_model as cm
     from recommendation_amd.r_model import RecommendationModel
-    from recommendation_amd.trainer import AdamOptimizer, train_step
+    from recommendation_amd.trainer import AdamOptimizer, GraphedTrainStep, train_step
     dev = torch.device('cuda', 0)
     B = args.batch if args.batch != 8192 else 300
     params = cm.init_params(seed=1, dtype=np.float32)
@@ -760,9 +760,13 @@ def bench_colour(args):
     host = [cm.synthetic_batch(B, seed=20211207 + j) for j in range(8)]
     batches = [tuple(torch.from_numpy(b[k]).to(dev) for k in cm._KEYS) for b in host]
     it = [0]
+    graphed = None if args.no_graph else GraphedTrainStep(m, opt, batches[0], check_every=64)
 
     def step():
-        train_step(m, opt, batches[it[0] % len(batches)])
+        if graphed is not None:
+            graphed(batches[it[0] % len(batches)])      # copies the batch into the graph's inputs, replays
+        else:
+            train_step(m, opt, batches[it[0] % len(batches)])
         it[0] += 1
 
     dt = _timed_steps(step, args)
@@ -770,6 +774,7 @@ def bench_colour(args):
     res = _line(args, 'colour_model_train_b%d' % B, B, dt, 'f32',
                 dict(model='RecommendationModel(128, 6, 100, 20)', parameters=5910, optimizer='adam_tf (dense, lr 1e-4)',
                      includes='encoders, 11 linear layers, softmax / top-6 / accuracy / loss, backward, Adam'))
+    res['config']['launch'] = 'eager' if graphed is None else 'hip graph replay (7 input copies + 1 replay per step)'
     # plumbing, not a bandwidth workload: a sample is 16 ids and 16 gathered rows (124 floats); the step is
     # bound by the launches of a 5,910-parameter model
     nbytes = B * (16 * 4 + 124 * 4 + 2 * 128 * 4) + 3 * 2 * 5910 * 4

@@ -134,6 +134,7 @@ class RecommendationModel(object):
         self.validate = validate
         self.check_every = 1
         self._feature_calls = 0
+        self._in_graph = False           # set while a step is captured / replayed as a HIP graph: no host reads
         self._gen = torch.Generator(device='cpu')
         self._gen.manual_seed(0 if seed is None else int(seed))
         self._arena = torch.zeros(0, dtype=torch.float32, device=self.device)
@@ -216,12 +217,16 @@ class RecommendationModel(object):
         if not self.validate:
             return
         if self._err is None:
+            if self._in_graph:
+                raise RuntimeError("the id error word must exist before a step is captured")
             self._err = ops.new_error_word(self.device)
         ops.validate_ids(self._table_offsets(size), 1, ids, flags, self._err, bag_len=ids.shape[-1] if ids.dim() > 1 else 1)
 
     def check_errors(self):
-        """Raise InvalidArgumentError if any id seen since the last check was invalid."""
-        if self._err is not None:
+        """Raise InvalidArgumentError if any id seen since the last check was invalid.  Inside a captured step
+        nothing is read back (the kernels still OR their findings into the error word); the owner of the graph
+        calls this between replays."""
+        if self._err is not None and not self._in_graph:
             ops.check_error_word(self._err)
 
     # -- reference API ------------------------------------------------------------------------

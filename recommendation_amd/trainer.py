@@ -77,10 +77,113 @@ def train_step(model, optimizer, columns, process_group=None):
     return acc, labels, top_indices_real, loss.detach(), global_step
 
 
+class GraphedTrainStep(object):
+    """``train_step`` for a fixed batch size captured ONCE as a HIP graph and replayed: the colour model's
+    step is ~150 launches of a 5,910-parameter model (encoder checks, 11 layers forward and backward through
+    autograd, heads, Adam), each a few microseconds of device work behind tens of microseconds of Python and
+    launch overhead, so the eager step is bound by the host.  Replaying the captured launches removes that;
+    the arithmetic is the same kernels in the same order, so results equal the eager step's bit for bit.
+
+    What a captured step cannot do is read anything back or take a scalar from the host, so
+    * Adam's step size lives on the device (mi_adam_schedule_step advances {alpha_t, beta1_power,
+      beta2_power} inside the graph; the host copy of the schedule is advanced beside it for checkpoints),
+    * the id error word is read every ``check_every`` replays (and by ``check()``) instead of in every
+      ``features`` call: a bad id is never dereferenced meanwhile, it is just reported a few steps later.
+    A batch of another size (the ragged last batch of an epoch) runs the eager step.  The tensors returned by
+    a replay are the graph's own output buffers: the next call overwrites them.  Single process only (the
+    data-parallel all-reduce is not captured)."""
+
+    def __init__(self, model, optimizer, columns, check_every=64):
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size() > 1:
+            raise RuntimeError("GraphedTrainStep is single-process; use train_step with a process group")
+        m = self.model = model
+        self.opt = optimizer
+        self.check_every = int(check_every)
+        self.calls = 0
+        self.static_in = tuple(m._ids(c).clone() for c in columns)
+        self.batch = int(self.static_in[0].shape[0])
+        features, labels = columns_to_features(self.static_in)
+        with torch.no_grad():                       # variables, table offsets and the error word exist before capture
+            m.input_to_one_hot_plus(labels, m.colour_count)
+            m.forward(m.features(features))
+        params = m.parameters()
+        optimizer._slots_for(params)
+        self.sched = torch.zeros(3, dtype=torch.float32, device=m.device)
+        self._sched_to_device()
+        saved = [t.detach().clone() for t in (params, optimizer.m, optimizer.v, self.sched)]
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        m._in_graph = True
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(3):                  # warm-up off the capture, then put everything back
+                    self._body()
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for dst, src in zip((params, optimizer.m, optimizer.v, self.sched), saved):
+                    dst.copy_(src)
+            params.grad = None
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._body()
+        finally:
+            m._in_graph = False
+
+    def _sched_to_device(self):
+        sch = self.opt._schedule
+        self.sched.copy_(torch.tensor([0.0, float(sch.b1p), float(sch.b2p)], dtype=torch.float32))
+
+    def _body(self):
+        m, opt = self.model, self.opt
+        features, labels = columns_to_features(self.static_in)
+        label_tensor = m.input_to_one_hot_plus(labels, m.colour_count)
+        fs = m.features(features)
+        last_layer = m.forward(fs)
+        top_indices, _ = m.output(last_layer)
+        top_indices_real = top_indices.to(torch.int32)
+        acc = m.accuracy(labels, top_indices_real, m.recommend_num)
+        loss = m.loss(logits=last_layer, labels=label_tensor)
+        params = m.parameters()
+        params.grad = None
+        loss.backward()
+        ops.adam_schedule_step(self.sched, opt.learning_rate, opt.beta1, opt.beta2)
+        ops.adam_tf_dense(params.detach(), opt.m, opt.v, params.grad.contiguous(), 0.0, opt.beta1, opt.beta2,
+                          opt.epsilon, lr_dev=self.sched)
+        return acc, top_indices_real, loss.detach()
+
+    def check(self):
+        self.model.check_errors()
+
+    def __call__(self, columns):
+        """Same result tuple as train_step: (acc, labels, top_indices, loss, global_step)."""
+        m = self.model
+        if int(columns[0].shape[0]) != self.batch:
+            res = train_step(m, self.opt, columns)
+            self._sched_to_device()
+            return res
+        for dst, src in zip(self.static_in, columns):
+            dst.copy_(src.reshape(dst.shape), non_blocking=True)
+        m._in_graph = True
+        try:
+            self.graph.replay()
+        finally:
+            m._in_graph = False
+        self.opt._schedule.step()                   # the host's copy of the schedule (checkpoints, global_step)
+        self.calls += 1
+        if self.check_every and self.calls % self.check_every == 0:
+            m.check_errors()
+        acc, top, loss = self.out
+        return acc, self.static_in[6], top, loss, self.opt.t
+
+
 def train(files, batch_size=300, last_step=5000, learning_rate=1e-4, device='cuda:0', seed=None, parallelism=None,
-          index=None, log_every=100, model=None, process_group=None):
+          index=None, log_every=100, model=None, process_group=None, graph=False):
     """The loop of local_train_utils.train (:30-66) / ModelTrainer.train's worker branch
-    (model_trainer.py:138-179): same model constants, batch size, optimizer and stop step."""
+    (model_trainer.py:138-179): same model constants, batch size, optimizer and stop step.
+    ``graph=True`` replays the step as a captured HIP graph (single process; see GraphedTrainStep)."""
     m = model or RecommendationModel(colour_count=128, recommend_num=6, user_count=100, country_count=20,
                                      device=device, seed=seed)
     dataset = Sample.read_label_data(files, batch_size=batch_size, parallelism=parallelism, index=index)
@@ -88,11 +191,19 @@ def train(files, batch_size=300, last_step=5000, learning_rate=1e-4, device='cud
     optimizer = AdamOptimizer(learning_rate=learning_rate)
     step = 0
     history = []
+    graphed = None
     while step < last_step:
         columns = iterator.get_next()
         step += 1
-        acc_res, _, _, loss_res, global_step_res = train_step(m, optimizer, columns, process_group)
+        if graph and process_group is None:
+            if graphed is None:
+                graphed = GraphedTrainStep(m, optimizer, columns)
+            acc_res, _, _, loss_res, global_step_res = graphed(columns)
+        else:
+            acc_res, _, _, loss_res, global_step_res = train_step(m, optimizer, columns, process_group)
         if log_every and step % log_every == 0:
             history.append((step, float(loss_res), float(acc_res)))
             print("Train step %d, loss: %f accuracy: %f" % (step, float(loss_res), float(acc_res)))
+    if graphed is not None:
+        graphed.check()
     return m, optimizer, history

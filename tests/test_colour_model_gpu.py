@@ -197,3 +197,48 @@ def test_train_loop_from_files_follows_the_oracle_trajectory(dev, tmp_path):
     assert hist[-1][1] < hist[0][1]
     for n in p64:
         assert rel_err(m.variables[n].cpu().numpy(), p64[n]) <= 1e-4, n
+
+
+def test_graphed_train_step_equals_eager_bit_for_bit(dev):
+    """The step replayed as a captured HIP graph (device-resident Adam schedule, id checks deferred) against the
+    eager step on a twin model: same kernels in the same order, so every result and every parameter is
+    bit-identical - over several batches, a ragged batch in between (which takes the eager path) included."""
+    from recommendation_amd.trainer import AdamOptimizer, GraphedTrainStep, train_step
+    params = oracle_params(11)
+    a, b = model_with(params, dev), model_with(params, dev)
+    opt_a, opt_b = AdamOptimizer(1e-3), AdamOptimizer(1e-3)
+    batches = [tuple(torch.from_numpy(v).to(dev) for v in cm.synthetic_batch(300, seed=40 + i).values())
+               for i in range(5)]
+    ragged = tuple(torch.from_numpy(v).to(dev) for v in cm.synthetic_batch(77, seed=99).values())
+    train_step(a, opt_a, batches[0])                 # the graph is captured from a model that has already stepped
+    train_step(b, opt_b, batches[0])
+    g = GraphedTrainStep(a, opt_a, batches[1], check_every=2)
+    assert torch.equal(a.parameters().detach(), b.parameters().detach())     # capturing moved nothing
+    for cols in (batches[1], batches[2], ragged, batches[3], batches[4]):
+        ra = g(cols)
+        rb = train_step(b, opt_b, cols)
+        assert ra[4] == rb[4]
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[2], rb[2]) and torch.equal(ra[3], rb[3])
+        assert torch.equal(a.parameters().detach(), b.parameters().detach())
+    assert torch.equal(opt_a.m, opt_b.m) and torch.equal(opt_a.v, opt_b.v)
+    assert opt_a.t == opt_b.t == 6
+    assert opt_a._schedule.b1p == opt_b._schedule.b1p
+    g.check()
+
+
+def test_graphed_train_step_reports_bad_ids_at_the_next_check(dev):
+    from recommendation_amd.ops import InvalidArgumentError
+    from recommendation_amd.trainer import AdamOptimizer, GraphedTrainStep
+    m = model_with(oracle_params(12), dev)
+    opt = AdamOptimizer(1e-3)
+    good = tuple(torch.from_numpy(v).to(dev) for v in cm.synthetic_batch(64, seed=50).values())
+    g = GraphedTrainStep(m, opt, good, check_every=0)
+    g(good)
+    g.check()
+    bad = list(t.clone() for t in good)
+    bad[0][3] = 100                                   # user id == user_count: out of range
+    before = m.parameters().detach().clone()
+    g(tuple(bad))                                     # nothing is read back inside the replay ...
+    with pytest.raises(InvalidArgumentError):
+        g.check()                                     # ... the report comes at the check
+    assert torch.isfinite(m.parameters()).all() and not torch.equal(before, m.parameters().detach())
