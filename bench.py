@@ -51,8 +51,10 @@ def parse_args():
     ap.add_argument('--stage-reps', type=int, default=50)
     ap.add_argument('--no-graph', action='store_true', help='launch the step eagerly instead of replaying a HIP graph')
     ap.add_argument('--prefetch', action='store_true',
-                    help='sharded path: route and exchange the ids of the next batch on a side stream beside this step\'s update '
-                         '(measured slower at world size 1: the extra stream hops cost more than the exchange they hide)')
+                    help='sharded path: route and exchange the ids of the next batch on a side stream beside this step\'s update; '
+                         'the default with more than one rank (measured slower at world size 1: the extra stream hops cost more '
+                         'than the exchange they hide)')
+    ap.add_argument('--no-prefetch', action='store_true', help='sharded path with several ranks: no next-batch id exchange beside the update')
     ap.add_argument('--din-full-rows', action='store_true',
                     help='DIN: materialise the full [q | k | q-k | q*k] rows instead of the factored first layer')
     ap.add_argument('--prefetch-sort', action='store_true',
@@ -952,7 +954,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         kw = kws[i % len(batches)]
-        if sharded and args.prefetch:   # the next batch's ids are routed and exchanged beside this step's update
+        if sharded and (args.prefetch or (world > 1 and not args.no_prefetch)):   # next batch's ids routed and exchanged beside this step's update
             kw = {'next_ids': batches[(i + 1) % len(batches)][0]}
         model.train_step(*batches[i % len(batches)], **kw)
     barrier()
@@ -980,6 +982,9 @@ def main():
                                 else 'inside the step'),
                        'parallelism': 'single' if not sharded else 'rowwise-sharded tables x%d + replicated dense' % world},
         }
+        if sharded:
+            result['config']['next_batch_id_exchange'] = ('beside the update (side stream)'
+                                                          if (args.prefetch or (world > 1 and not args.no_prefetch)) else 'in front of the step')
     if not sharded:
         stages, U = stage_report(model, batches, args.stage_reps, args.idx_bits, tms)
         hbm = [s for s in stages if s['name'].startswith(('fm_fwd', 'fm_bwd_apply'))]

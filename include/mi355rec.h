@@ -358,6 +358,32 @@ int mi_fm_bwd_apply_dense(const mi_bwd_plan* plan, const mi_fm_table* tab, const
 int mi_adam_schedule_step(float* sched, float lr, float beta1, float beta2, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Collectives over RCCL (xGMI inside a node), one communicator per process / GPU.
+ * They replace the reference's parameter-server traffic (model_trainer.py:124-136: every variable
+ * read and optimizer apply is a gRPC hop to the ps task; train_job.py:41-42 starts the workers)
+ * for hosts that do not go through torch.distributed: the exchanges of the row-wise sharded tables
+ * and the sum of replicated dense gradients.  Every call enqueues on `stream` and returns; counts
+ * are fixed per rank pair (no size negotiation, nothing on the host waits for the device).
+ * RCCL is resolved with dlopen at the first call (a copy the process already holds is reused);
+ * without it the calls return MI_ERR_UNSUPPORTED.
+ *   mi_comm_unique_id   rank 0 fills 128 bytes that the host hands to every rank (file, socket, MPI ...)
+ *   mi_comm_init        collective over all ranks: ncclCommInitRank on the current device
+ *   mi_a2a_indices      recv[s][i] = rank s's send[me][i], int32 (slot blocks / id lists)
+ *   mi_a2a_pooled       the same for fp32 rows (partial pools, pooled rows, gradient rows)
+ *   mi_allgather_bytes  recv[s] = rank s's send, bytes_per_rank each
+ *   mi_allreduce_dense  buf <- sum over ranks, in place, fp32 (dense gradients of replicated weights)
+ * ---------------------------------------------------------------------------------- */
+#define MI_COMM_ID_BYTES 128
+int mi_comm_unique_id(void* id_out);
+int mi_comm_init(const void* unique_id, int n_ranks, int rank, void** comm_out);
+int mi_comm_destroy(void* comm);
+int mi_comm_size(const void* comm, int* n_ranks, int* rank);
+int mi_a2a_indices(void* comm, const int32_t* send, int32_t* recv, int64_t ints_per_pair, void* stream);
+int mi_a2a_pooled(void* comm, const float* send, float* recv, int64_t floats_per_pair, void* stream);
+int mi_allgather_bytes(void* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+int mi_allreduce_dense(void* comm, float* buf, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Row-wise sharded tables (N ranks, one process per GPU).  Global row r = table_offsets[t] + id
  * lives on rank r % N as local row r / N.  Replaces the parameter-server variable traffic of
  * model_trainer.py:124-136 (every variable read and every Adam apply a gRPC hop to the ps task).

@@ -17,6 +17,7 @@ MI_POOL_SUM, MI_POOL_MEAN = 0, 1
 MI_DT_F32, MI_DT_BF16 = 0, 1
 MI_OPT_SGD, MI_OPT_ADAGRAD_ROWWISE, MI_OPT_ADAM_TF = 0, 1, 2
 MI_NOALLOC_MAX_ENTRIES = 1 << 21
+MI_COMM_ID_BYTES = 128
 
 
 class MiError(RuntimeError):
@@ -129,6 +130,14 @@ _SIGNATURES = {
     'mi_shard_bag_combine': (c_int, [P, P, c_int, c_int64, c_int, c_int, P, c_int64, P]),
     'mi_shard_bag_pack': (c_int, [P, c_int64, c_int, c_int, P, P, c_int, c_int64, P, P]),
     'mi_embag_bwd_apply_rows': (c_int, [POINTER(BwdPlan), P, P, c_int, c_int, P, P, c_float, c_float, P]),
+    'mi_comm_unique_id': (c_int, [P]),
+    'mi_comm_init': (c_int, [P, c_int, c_int, POINTER(c_void_p)]),
+    'mi_comm_destroy': (c_int, [P]),
+    'mi_comm_size': (c_int, [P, POINTER(c_int), POINTER(c_int)]),
+    'mi_a2a_indices': (c_int, [P, P, P, c_int64, P]),
+    'mi_a2a_pooled': (c_int, [P, P, P, c_int64, P]),
+    'mi_allgather_bytes': (c_int, [P, P, P, c_int64, P]),
+    'mi_allreduce_dense': (c_int, [P, P, c_int64, P]),
     'mi_fm_dense_step_rows': (c_int, [P, c_int, c_int, c_int, c_int64, P, P, P, c_float, P, c_float, c_float,
                                       c_float, P, P]),
 }

@@ -118,6 +118,65 @@ class TorchComm(object):
         dist.all_gather_into_tensor(out, inp, group=self.group)
 
 
+class RcclComm(object):
+    """The same collectives through the library's own RCCL entry points (mi_comm_*, mi_a2a_*,
+    mi_allgather_bytes, mi_allreduce_dense) instead of torch.distributed: what a host without
+    PyTorch's process groups would call.  The 128-byte RCCL id is made by rank 0 and handed round
+    by ``exchange_id(id_bytes_or_None) -> id_bytes`` (default: torch.distributed's object
+    broadcast when a process group is up; a single rank needs no exchange)."""
+
+    def __init__(self, rank=None, world=None, exchange_id=None):
+        import ctypes
+        from . import _lib
+        if rank is None:
+            up = dist.is_available() and dist.is_initialized()
+            rank, world = (dist.get_rank(), dist.get_world_size()) if up else (0, 1)
+        self.rank, self.world = int(rank), int(world)
+        buf = ctypes.create_string_buffer(_lib.MI_COMM_ID_BYTES)
+        if self.rank == 0:
+            _lib.call('mi_comm_unique_id', buf)
+        if self.world > 1:
+            if exchange_id is None:
+                box = [bytes(buf.raw) if self.rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                ident = box[0]
+            else:
+                ident = exchange_id(bytes(buf.raw) if self.rank == 0 else None)
+            buf = ctypes.create_string_buffer(ident, _lib.MI_COMM_ID_BYTES)
+        self._h = ctypes.c_void_p()
+        _lib.call('mi_comm_init', buf, self.world, self.rank, ctypes.byref(self._h))
+
+    @staticmethod
+    def _stream():
+        import ctypes
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def all_to_all(self, out, inp):
+        from . import _lib
+        n = inp.numel() // self.world
+        if inp.dtype == torch.float32:
+            _lib.call('mi_a2a_pooled', self._h, inp.data_ptr(), out.data_ptr(), n, self._stream())
+        elif inp.dtype == torch.int32:
+            _lib.call('mi_a2a_indices', self._h, inp.data_ptr(), out.data_ptr(), n, self._stream())
+        else:
+            raise ops.MiError("RcclComm.all_to_all: int32 or float32 blocks only")
+
+    def all_gather(self, out, inp):
+        from . import _lib
+        _lib.call('mi_allgather_bytes', self._h, inp.data_ptr(), out.data_ptr(), inp.numel() * inp.element_size(),
+                  self._stream())
+
+    def all_reduce(self, buf):
+        from . import _lib
+        _lib.call('mi_allreduce_dense', self._h, buf.data_ptr(), buf.numel(), self._stream())
+
+    def close(self):
+        from . import _lib
+        if self._h:
+            _lib.call('mi_comm_destroy', self._h)
+            self._h = None
+
+
 class ShardedFactorizationMachine(object):
     def __init__(self, rows_per_table, dim, n_dense, device, opt='adam_tf', lr=1e-3, beta1=0.9, beta2=0.999,
                  eps=1e-8, seed=0, init_scale=0.05, comm=None, backend=None, rank=None, world=None):

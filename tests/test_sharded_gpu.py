@@ -276,3 +276,36 @@ def test_train_step_over_rccl_world1_with_and_without_prefetch(dev):
             m.be.check()
     finally:
         dist.destroy_process_group()
+
+
+def test_train_step_over_the_librarys_own_rccl_entry_points_world1(dev):
+    """The same step with every collective going through the C ABI's RCCL entry points (mi_comm_init,
+    mi_a2a_indices, mi_a2a_pooled, mi_allgather_bytes; RcclComm) instead of torch.distributed: one rank,
+    bit-equal to the lockstep driver.  mi_allreduce_dense over one rank leaves the buffer as it is."""
+    from recommendation_amd.sharded import RcclComm, ShardedFactorizationMachine, lockstep_train_step
+    comm = RcclComm(rank=0, world=1)
+    try:
+        rows = [1460, 583, 30001, 305, 24, 3, 10, 4]
+        ref = ofm.State(rows, 16, 13, seed=6, opt="adam_tf")
+        m = ShardedFactorizationMachine(rows, 16, 13, device=dev, opt="adam_tf", lr=1e-2, comm=comm)
+        lock = ShardedFactorizationMachine(rows, 16, 13, device=dev, opt="adam_tf", lr=1e-2, rank=0, world=1)
+        for x in (m, lock):
+            x.load_state(ref)
+        for s in range(3):
+            b = tuple(torch.from_numpy(a).to(dev) for a in ofm.synthetic_batch(1024, rows, 13, seed=10 + s, dist='zipf'))
+            assert torch.equal(m.train_step(*b), lockstep_train_step([lock], [b]))
+        torch.cuda.synchronize()
+        assert torch.equal(m.be.table.rec, lock.be.table.rec) and torch.equal(m.dp, lock.dp)
+        m.be.check()
+        g = torch.arange(1000, dtype=torch.float32, device=dev) * 0.25
+        want = g.clone()
+        comm.all_reduce(g)
+        torch.cuda.synchronize()
+        assert torch.equal(g, want)
+        ints = torch.arange(77, dtype=torch.int32, device=dev)
+        out = torch.empty_like(ints)
+        comm.all_to_all(out, ints)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ints)
+    finally:
+        comm.close()
