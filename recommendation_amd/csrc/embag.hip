@@ -54,6 +54,12 @@ __device__ __forceinline__ void st_out(void* out, int64_t off, const Acc<VEC>& a
 
 constexpr int EMBAG_BLOCK = 256;
 constexpr int UNROLL = 4;
+#ifndef MI_EMBAG_WAVE_MIN_LEN
+#define MI_EMBAG_WAVE_MIN_LEN 16
+#endif
+#ifndef MI_EMBAG_WAVE_MAX_THREADS
+#define MI_EMBAG_WAVE_MAX_THREADS (8 * 64 * 4 * 256)  // 8 waves on each of the chip's 1,024 SIMDs
+#endif
 
 template <typename IDX, int VEC, bool BF16>
 __global__ __launch_bounds__(EMBAG_BLOCK) void embag_fwd_kernel(
@@ -217,6 +223,103 @@ __global__ __launch_bounds__(EMBAG_BLOCK) void embag_fwd_l1_kernel(
   if (bad && c == 0 && err) atomicOr(err, bad);
 }
 
+// Multi-hot bags of sixteen ids or more when the batch alone does not fill the chip: ONE WAVE per bag.  The
+// lane-group kernel above walks a bag four ids per round, so a 100-id bag is 25 dependent pairs of round trips
+// and only many bags in flight hide them.  Here the wave loads 64 of the bag's ids with one coalesced
+// instruction, checks them (range against the table, strictly-increasing order against the neighbour lane),
+// stages the rows they name in wave-private LDS, and its 64 / lanes lane groups then take the rows WAVE_ROWS at
+// a time, all requested before the first is added.  A shuffle tree over the lane groups (a wave64 segment
+// reduction: the segments are the columns) leaves the pooled row in group 0.  The order of additions depends
+// only on the bag's length.  Needs lanes = dim / 4 to be a power of two <= 64.
+constexpr int WAVE_ROWS = 8;
+template <typename IDX, bool BF16>
+__global__ __launch_bounds__(EMBAG_BLOCK) void embag_fwd_wave_kernel(
+    const float* __restrict__ weights, const int64_t* __restrict__ toffs, int T, int dim, int lanes,
+    const void* __restrict__ indices, int bag_len, int n_bags, int pool_mode, int flags,
+    const float* __restrict__ bias, void* __restrict__ out, int64_t out_ld, int32_t* __restrict__ err) {
+  __shared__ int64_t rows_lds[EMBAG_BLOCK / 64][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int bag = blockIdx.x * (EMBAG_BLOCK / 64) + w;
+  if (bag >= n_bags) return;  // uniform over the wave
+  const int G = 64 / lanes, g = lane / lanes, c = lane - g * lanes;
+  const int b = bag / T, t = bag - b * T;
+  const int64_t base = toffs[t];
+  const int64_t rows = toffs[t + 1] - base;
+  const int64_t beg = (int64_t) bag * bag_len;
+  int64_t* __restrict__ rl = rows_lds[w];
+  Acc<4> acc;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc.v[k] = 0.f;
+  int count = 0, bad = 0;
+  int64_t carry = -1;  // the last non-negative id of the chunks before (order check)
+  const float* wcol = weights + (int64_t) c * 4;
+  for (int j0 = 0; j0 < bag_len; j0 += 64) {  // uniform
+    const int nj = bag_len - j0 < 64 ? bag_len - j0 : 64;
+    const bool present = lane < nj;
+    const int64_t id = mi_ld_id<IDX>(indices, beg + j0 + (present ? lane : 0));
+    const bool nonneg = present && id >= 0;
+    if (present && id < 0 && (flags & MI_CHECK_NONNEG)) bad |= MI_IDERR_RANGE;
+    if (nonneg && id >= rows && (flags & MI_CHECK_RANGE)) bad |= MI_IDERR_RANGE;
+    if (flags & MI_CHECK_INCREASING) {
+      // the id before mine that is not padding: the nearest non-negative one in lower lanes, else the carry
+      const unsigned long long nn = __ballot(nonneg);
+      const unsigned long long below = lane ? (nn & (~0ull >> (64 - lane))) : 0ull;
+      const int src = below ? 63 - __clzll((long long) below) : 0;
+      const int64_t lo32 = (int64_t) (uint32_t) __shfl((int) (uint32_t) id, src, 64);
+      const int64_t hi32 = (int64_t) __shfl((int) (id >> 32), src, 64);
+      const int64_t prev = below ? ((hi32 << 32) | lo32) : carry;
+      if (nonneg && id <= prev) bad |= MI_IDERR_ORDER;
+      const int last = nn ? 63 - __clzll((long long) nn) : 0;
+      const int64_t l_lo = (int64_t) (uint32_t) __shfl((int) (uint32_t) id, last, 64);
+      const int64_t l_hi = (int64_t) __shfl((int) (id >> 32), last, 64);
+      if (nn) carry = (l_hi << 32) | l_lo;
+    }
+    const bool ok = nonneg && id < rows;  // an id outside the table is never dereferenced
+    count += __popcll(__ballot(ok));
+    rl[lane] = ok ? base + id : -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e0 = 0; e0 < nj; e0 += WAVE_ROWS * G) {  // uniform
+      int64_t row[WAVE_ROWS];
+      Acc<4> r[WAVE_ROWS];
+#pragma unroll
+      for (int u = 0; u < WAVE_ROWS; ++u) {
+        const int e = e0 + u * G + g;
+        row[u] = e < nj ? rl[e] : -1;
+        ld_row<4>(wcol + (row[u] >= 0 ? row[u] : 0) * dim, r[u]);  // no branch around the load; masked below
+      }
+#pragma unroll
+      for (int u = 0; u < WAVE_ROWS; ++u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc.v[k] += row[u] >= 0 ? r[u].v[k] : 0.f;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the rows are consumed before the next chunk overwrites them
+  }
+  for (int o = lanes; o < 64; o <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc.v[k] += __shfl_xor(acc.v[k], o, 64);
+  }
+  if (pool_mode == MI_POOL_MEAN && count > 1) {
+    const float inv = 1.0f / (float) count;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc.v[k] *= inv;
+  }
+  if (g == 0) {
+    if (bias) {
+      Acc<4> bv;
+      ld_row<4>(bias + (int64_t) t * dim + (int64_t) c * 4, bv);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc.v[k] += bv.v[k];
+    }
+    st_out<4, BF16>(out, (int64_t) b * out_ld + (int64_t) t * dim + (int64_t) c * 4, acc);
+  }
+  bad |= __shfl_xor(bad, 32, 64);
+  for (int o = 16; o > 0; o >>= 1) bad |= __shfl_xor(bad, o, 64);
+  if (bad && lane == 0 && err) atomicOr(err, bad);
+}
+
 template <typename IDX>
 __global__ __launch_bounds__(256) void onehot_dense_kernel(const void* __restrict__ indices, int bag_len,
                                                           int n_bags, int size, int flags,
@@ -339,6 +442,21 @@ int launch_fwd(const float* weights, const int64_t* toffs, int T, int dim, const
     else if (nt) L1(false, true);
     else L1(false, false);
 #undef L1
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+  }
+  // bags of 16 ids or more, too few of them for the lane-group kernel's serial rounds to hide behind one
+  // another (fewer than ~8 waves per SIMD of lane groups): one wave per bag
+  // (and at least four rounds of rows per lane group: with 64 / lanes groups a short bag leaves most of a round's
+  // loads masked - measured slower than the lane-group kernel at 20 ids of dim 16)
+  if (vec4 && !offsets && bag_len >= MI_EMBAG_WAVE_MIN_LEN && (lanes & (lanes - 1)) == 0 && lanes <= 64 &&
+      bag_len >= 4 * (64 / lanes) && (int64_t) n_bags * lanes < (int64_t) MI_EMBAG_WAVE_MAX_THREADS) {
+    const unsigned wgrid = (unsigned) mi_cdiv(n_bags, EMBAG_BLOCK / 64);
+#define WAVE(BF)                                                                                                    \
+  hipLaunchKernelGGL((embag_fwd_wave_kernel<IDX, BF>), dim3(wgrid), dim3(EMBAG_BLOCK), 0, s, weights, toffs, T, dim, \
+                     lanes, indices, bag_len, n_bags, pool_mode, flags, bias, out, out_ld, err)
+    if (out_dtype == MI_DT_BF16) WAVE(true); else WAVE(false);
+#undef WAVE
     MI_LAUNCH_CHECK();
     return MI_OK;
   }

@@ -7,6 +7,9 @@
 extern "C" int mi_debug_seg_trace(unsigned long long* host_out, int n) {
   return (int) hipMemcpyFromSymbol(host_out, HIP_SYMBOL(seg_trace_buf), (size_t) n * 8);
 }
+extern "C" int mi_debug_seg_phases(unsigned long long* host_out, int n) {
+  return (int) hipMemcpyFromSymbol(host_out, HIP_SYMBOL(seg_phase_buf), (size_t) n * 8);
+}
 #endif
 
 template <class Extra>

@@ -781,6 +781,18 @@ struct FmDenseFinalExtra {
 };
 static_assert(FM_DENSE_THREADS == UBLOCK, "the dense side runs in workgroups of the sparse update's size");
 
+#ifdef SEG_TRACE
+static __device__ unsigned long long seg_trace_buf[4096 * 2];  // one copy per translation unit
+static __device__ unsigned long long seg_phase_buf[4096 * 8];  // phase stamps of the long-run workgroups
+#define SEG_PHASE(k)                                                                                  \
+  do {                                                                                                \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) seg_phase_buf[blockIdx.x * 8 + (k)] = wall_clock64();  \
+  } while (0)
+#else
+#define SEG_PHASE(k)
+#endif
+
 // LP: lanes per row when that is 1, 2 or 4 (rows of up to 16 floats: only the LDS path for the short runs
 // is compiled, which keeps the kernel under 128 vector registers - four waves per SIMD instead of
 // three), 0 for any other width (lanes is then read from the argument).
@@ -845,6 +857,7 @@ __device__ __forceinline__ void seg_sorted_body(PlanDev pl, Src src, Upd upd, in
     }
     __syncthreads();
     const int nh = sh_n;
+    SEG_PHASE(0);  // scan done
     if (threadIdx.x == 0) {  // ascending position: the order a workgroup takes its runs in must not depend on timing
       for (int x = 1; x < nh; ++x) {
         const int v = sh_heads[x];
@@ -859,6 +872,7 @@ __device__ __forceinline__ void seg_sorted_body(PlanDev pl, Src src, Upd upd, in
     // runs of ~300, three or four heads per chunk) works on them side by side instead of one after
     // the other with all its threads and a dozen barriers each.
     __shared__ int sh_done[LONG_CAP], sh_ends[LONG_CAP];
+    SEG_PHASE(1);  // heads in order
     for (int h = threadIdx.x >> 6; h < nh; h += UBLOCK / 64) {  // uniform over the wave
       const int hv = sh_heads[h];
       int done = 0, hend_out = -1;
@@ -877,6 +891,7 @@ __device__ __forceinline__ void seg_sorted_body(PlanDev pl, Src src, Upd upd, in
       }
     }
     __syncthreads();
+    SEG_PHASE(2);  // wave-dealt heads done (searches, runs of up to WAVE_RUN_MAX)
     // A long run is summed in pieces, one per LONG_CHUNK it touches, each by the workgroup of that
     // chunk, so that a row hit by a large part of the batch does not keep ONE workgroup busy while
     // the rest of the chip is done.  Piece h = -1: the run that enters this chunk from the left.
@@ -1130,9 +1145,7 @@ __device__ __forceinline__ void seg_sorted_body(PlanDev pl, Src src, Upd upd, in
   for (int r = 0; r * G < nheads; ++r) one_head(r * G + g);  // uniform over the wave
 }
 
-#ifdef SEG_TRACE
-static __device__ unsigned long long seg_trace_buf[4096 * 2];  // one copy per translation unit
-#endif
+
 
 template <int VEC, bool SPLIT, int LP, class Src, class Upd, class Extra>
 __global__ __launch_bounds__(UBLOCK) void seg_sorted_kernel(PlanDev pl, Src src, Upd upd, int lanes_arg, int groups,

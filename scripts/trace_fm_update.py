@@ -53,3 +53,18 @@ print("latest long-run workgroups (chunk: end us, duration us):", [(int(c), roun
 sh = np.argsort(-(en[n_dense_wg + n_long:]))[:12]
 print("latest wave workgroups (index: end us, duration us):", [(int(c), round(float(en[n_dense_wg + n_long + c]), 2), round(float(en[n_dense_wg + n_long + c] - st[n_dense_wg + n_long + c]), 2)) for c in sh])
 print("launch span %.2f us" % en.max())
+if hasattr(lib, 'mi_debug_seg_phases'):
+    lib.mi_debug_seg_phases.restype = ctypes.c_int
+    lib.mi_debug_seg_phases.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    ph = np.zeros(4096 * 8, dtype=np.uint64)
+    assert lib.mi_debug_seg_phases(ph.ctypes.data, 4096 * 8) == 0
+    ph = ph.reshape(4096, 8).astype(np.int64)
+    buf = np.zeros(4096 * 2, dtype=np.uint64)
+    lib.mi_debug_seg_trace(buf.ctypes.data, 4096 * 2)
+    t = buf.reshape(4096, 2).astype(np.int64)
+    print("long-run workgroups of the last step (chunk: start, scan done, heads ordered, wave-dealt heads done, end; us from launch start):")
+    t0 = t[:n_dense_wg + n_long + 832, 0].min()
+    for c in list(lng[:6]) + [0, 100]:
+        w = n_dense_wg + int(c)
+        print("  chunk %3d: %5.2f %5.2f %5.2f %5.2f %5.2f" % (c, (t[w, 0] - t0) / 100.0, (ph[w, 0] - t0) / 100.0, (ph[w, 1] - t0) / 100.0,
+                                                          (ph[w, 2] - t0) / 100.0, (t[w, 1] - t0) / 100.0))

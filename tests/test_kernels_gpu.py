@@ -241,6 +241,68 @@ def test_dense_grad_equals_onehot_transpose_times_dy(dev, mode, dim):
     assert rel_err(dW.cpu().numpy(), expect) <= RTOL
 
 
+@pytest.mark.parametrize("mode", ["sum", "mean"])
+@pytest.mark.parametrize("dim,L,idt", [(16, 64, np.int32), (64, 37, np.int64), (128, 64, np.int64), (128, 100, np.int32),
+                                       (32, 130, np.int64), (8, 150, np.int32), (16, 20, np.int64)])
+def test_wave_per_bag_forward_equals_oracle(dev, mode, dim, L, idt):
+    """Bags of 16 ids or more in a small batch take the one-wave-per-bag kernel (64 ids per coalesced load, rows staged
+    in LDS, shuffle tree over the lane groups): pooled rows against the oracle, padding ids, a bias, bf16 output."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(70 + L)
+    rows = [500, 7, 3000]
+    T, B = len(rows), 41
+    toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    w = rng.standard_normal((int(toffs[-1]), dim)).astype(np.float32)
+    ids = np.stack([rng.integers(-1, r, size=(B, L)) for r in rows], axis=1).astype(idt)
+    ids[3, 1, :] = -1                                       # a bag of padding only
+    bias = rng.standard_normal((T, dim)).astype(np.float32)
+    pm = ops.MI_POOL_MEAN if mode == "mean" else ops.MI_POOL_SUM
+    err = ops.new_error_word(dev)
+    got = ops.embag_fwd(torch.from_numpy(w).to(dev), torch.from_numpy(toffs).to(dev), T, torch.from_numpy(ids).to(dev),
+                        bag_len=L, pool_mode=pm, check_flags=ops.MI_CHECK_RANGE, bias=torch.from_numpy(bias).to(dev), err=err)
+    want = oe.embag_fwd(w, toffs, T, ids, bag_len=L, mode=mode) + bias.reshape(1, -1)
+    assert rel_err(got.cpu().numpy(), want) <= RTOL
+    ops.check_error_word(err)
+    got16 = ops.embag_fwd(torch.from_numpy(w).to(dev), torch.from_numpy(toffs).to(dev), T, torch.from_numpy(ids).to(dev),
+                          bag_len=L, pool_mode=pm, out_dtype=torch.bfloat16)
+    assert rel_err(got16.float().cpu().numpy(), want - bias.reshape(1, -1)) <= 1e-2
+
+
+def test_wave_per_bag_forward_reports_bad_ids(dev):
+    """Range and strictly-increasing checks of the wave kernel, also across its 64-id chunks (an order violation
+    between ids 63 and 64 of a bag, padding ids in between skipped as the reference's validate_indices would)."""
+    from recommendation_amd import ops
+    toffs = torch.tensor([0, 1000], dtype=torch.int64, device=dev)
+    w = torch.zeros((1000, 16), dtype=torch.float32, device=dev)
+    L = 100
+    good = np.sort(np.random.default_rng(3).choice(1000, size=(5, L), replace=False), axis=1).astype(np.int32)
+    flags = ops.MI_CHECK_RANGE | ops.MI_CHECK_INCREASING
+
+    def run(ids):
+        err = ops.new_error_word(dev)
+        ops.embag_fwd(w, toffs, 1, torch.from_numpy(ids).to(dev), bag_len=L, check_flags=flags, err=err)
+        ops.check_error_word(err)
+
+    run(good)
+    padded = good.copy()
+    padded[2, 10:20] = -1                                   # padding inside a bag does not break the order
+    run(padded)
+    for pos in (1, 63, 64, 99):
+        bad = good.copy()
+        bad[4, pos] = bad[4, pos - 1]                       # a repeated id
+        with pytest.raises(ops.InvalidArgumentError):
+            run(bad)
+    across = good.copy()
+    across[1, 60:64] = -1                                   # the neighbour across the chunk border is padding:
+    across[1, 64] = across[1, 59]                           # the last real id before it still counts
+    with pytest.raises(ops.InvalidArgumentError):
+        run(across)
+    out_of_range = good.copy()
+    out_of_range[0, 99] = 1000
+    with pytest.raises(ops.InvalidArgumentError):
+        run(out_of_range)
+
+
 @pytest.mark.parametrize("csr", [False, True])
 def test_bag_info_gives_the_bits_of_per_entry_recounting(dev, csr):
     """mi_embag_bag_info's per-bag scale and per-position bag (what SortedPlan hands the apply calls) against the
