@@ -482,7 +482,9 @@ def bench_embag(args):
     kern = 'embag_fwd_kernel' if dom is stages[0] else 'seg_sorted_kernel'
     res['roofline'] = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': round(dom['gbs'] / HBM_PEAK_GBS, 4),
-                       'traffic': _pmc_traffic('r01_embag_b65536_%s_pmc.json' % opt, res['config']['workload'], kern),
+                       'traffic': (_pmc_traffic('r02_embag_b65536_%s_pmc.json' % opt, res['config']['workload'], kern) or
+                                   _pmc_traffic('r01_embag_b65536_%s_pmc.json' % opt, res['config']['workload'], kern)),
+                       'traffic_source': 'quoted profiles/r0x_embag_b65536_%s_pmc.json (null when absent or another workload)' % opt,
                        'alg_bytes_per_launch': dom['alg_bytes'], 'ms_per_launch': dom['ms']}
     if not args.no_cpu_baseline:
         from oracle import embedding as oe

@@ -445,12 +445,15 @@ int launch_fwd(const float* weights, const int64_t* toffs, int T, int dim, const
     MI_LAUNCH_CHECK();
     return MI_OK;
   }
-  // bags of 16 ids or more, too few of them for the lane-group kernel's serial rounds to hide behind one
-  // another (fewer than ~8 waves per SIMD of lane groups): one wave per bag
+  // bags of 16 ids or more: one wave per bag when the launch is too small for the lane-group kernel's serial
+  // rounds to hide behind one another (fewer than ~8 waves per SIMD of lane groups), and at any size once a bag
+  // gives every lane group six rows or more (measured level or ahead there: +17 % at 100 ids of dim 16, +1-5 %
+  // at dim 64 / 128; behind by 3-8 % at 20 ids of dim 64, which this rule leaves to the lane-group kernel)
   // (and at least four rounds of rows per lane group: with 64 / lanes groups a short bag leaves most of a round's
   // loads masked - measured slower than the lane-group kernel at 20 ids of dim 16)
   if (vec4 && !offsets && bag_len >= MI_EMBAG_WAVE_MIN_LEN && (lanes & (lanes - 1)) == 0 && lanes <= 64 &&
-      bag_len >= 4 * (64 / lanes) && (int64_t) n_bags * lanes < (int64_t) MI_EMBAG_WAVE_MAX_THREADS) {
+      bag_len >= 4 * (64 / lanes) &&
+      ((int64_t) n_bags * lanes < (int64_t) MI_EMBAG_WAVE_MAX_THREADS || bag_len >= 6 * (64 / lanes))) {
     const unsigned wgrid = (unsigned) mi_cdiv(n_bags, EMBAG_BLOCK / 64);
 #define WAVE(BF)                                                                                                    \
   hipLaunchKernelGGL((embag_fwd_wave_kernel<IDX, BF>), dim3(wgrid), dim3(EMBAG_BLOCK), 0, s, weights, toffs, T, dim, \

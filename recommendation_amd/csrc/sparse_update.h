@@ -309,13 +309,15 @@ struct FmUpd {
 // Sum of the gradient sources of entries beg, beg+step, ... < end (fixed order).  Rounds of
 // eight: the permutation entries of round r+1 are requested before the sources of round r are
 // consumed, so a round costs one dependent memory round trip, not two.
-template <int VEC, class Src>
-__device__ __forceinline__ void sum_run(const PlanDev& pl, const Src& src, int c, int beg, int end, int step,
-                                        float* acc, float& sc) {
 #ifndef MI_SUM_UR
 #define MI_SUM_UR 8
 #endif
-  constexpr int UR = MI_SUM_UR;
+#ifndef MI_LONG_UR
+#define MI_LONG_UR 8
+#endif
+template <int VEC, class Src, int UR = MI_SUM_UR>
+__device__ __forceinline__ void sum_run(const PlanDev& pl, const Src& src, int c, int beg, int end, int step,
+                                        float* acc, float& sc) {
   if (beg >= end) return;
   int p[UR];
   bool in[UR];
@@ -362,6 +364,30 @@ __device__ __forceinline__ int run_end_wave(const uint32_t* keys, int n, int beg
   const int lane = threadIdx.x & 63;
   int lo = beg + 1, hi = n;  // answer in [lo, hi]
   bool first = true;
+#ifdef MI_WIDE_SEARCH
+  if (hi - lo > 1024) {
+    // first look 4096 entries ahead in ONE round trip: lane l probes entries lo + (l + 64 j) * 16, j = 0..3
+    uint32_t k[4];
+    bool gt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = lo + (lane + 64 * j) * 16;
+      k[j] = keys[idx < hi ? idx : lo];
+      gt[j] = idx >= hi;
+    }
+    int P = 256;  // first probe (in order j-major) beyond the run; uniform
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+      const unsigned long long m = __ballot(gt[j] || k[j] > row);
+      if (m) P = 64 * j + __ffsll((long long) m) - 1;
+    }
+    const int new_hi = P < 256 ? min(hi, lo + P * 16) : hi;
+    const int new_lo = P > 0 ? lo + (P - 1) * 16 + 1 : lo;
+    lo = new_lo;
+    hi = new_hi;
+    first = false;
+  }
+#endif
   while (lo < hi) {
     const int span = hi - lo;
     int step = (span + 63) / 64;
@@ -417,7 +443,7 @@ __device__ __forceinline__ void wave_run(const PlanDev& pl, const Src& src, cons
 #pragma unroll
   for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
   float sc = 0.f;
-  sum_run<VEC>(pl, src, c, beg + sub, end, wgroups, acc, sc);
+  sum_run<VEC, Src, MI_LONG_UR>(pl, src, c, beg + sub, end, wgroups, acc, sc);
   for (int o = lanes; o < 64; o <<= 1) {
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
@@ -587,7 +613,7 @@ __device__ __forceinline__ void block_sum(const PlanDev& pl, const Src& src, int
   for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
   float sc = 0.f;
   if (active) {
-    sum_run<VEC>(pl, src, c, beg + sub, end, groups, acc, sc);
+    sum_run<VEC, Src, MI_LONG_UR>(pl, src, c, beg + sub, end, groups, acc, sc);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) red[(sub * lanes + c) * VEC + k] = acc[k];
     reds[sub * lanes + c] = sc;
@@ -806,12 +832,22 @@ __device__ __forceinline__ void seg_sorted_body(PlanDev pl, Src src, Upd upd, in
   if (pl.n_dev) pl.n = min(pl.n, pl.n_dev[0]);
   const uint32_t* keys = pl.sorted_rows;
   const uint32_t sentinel = pl.sentinel;
+#ifdef MI_EXTRA_LAST
+  const int extra_first = (int) gridDim.x - extra.blocks;
+  if ((int) blockIdx.x >= extra_first) {
+    __shared__ float sh[UBLOCK];
+    extra.run(blockIdx.x - extra_first, sh);
+    return;
+  }
+  const int bid = blockIdx.x;
+#else
   if ((int) blockIdx.x < extra.blocks) {
     __shared__ float sh[UBLOCK];
     extra.run(blockIdx.x, sh);
     return;
   }
   const int bid = blockIdx.x - extra.blocks;
+#endif
   if (bid < long_blocks) {
     __shared__ float red[UBLOCK * VEC];
     __shared__ float reds[UBLOCK];

@@ -47,7 +47,8 @@ for L in (20, 100):
         a = out.clone()
         t_csr = timed(lambda: ops.embag_fwd(W, toffs, T, ids.view(-1), offsets=offs, check_flags=ops.MI_CHECK_RANGE, err=err, out=out))
         rel = float((a - out).abs().max() / out.abs().max())
-        wave = B * T * (D // 4) < 8 * 64 * 4 * 256 and L >= 4 * (64 // (D // 4))
+        G = 64 // (D // 4)
+        wave = L >= 16 and L >= 4 * G and (B * T * (D // 4) < 8 * 64 * 4 * 256 or L >= 6 * G)
         print("L %3d B %6d: fixed-length call (%s) %8.1f us %5.2f TB/s | lane-group kernel %8.1f us %5.2f TB/s | max rel diff %.1e"
               % (L, B, 'wave per bag' if wave else 'lane group  ', t_fixed, nbytes / t_fixed / 1e6, t_csr, nbytes / t_csr / 1e6, rel))
 ops.check_error_word(err)

@@ -43,6 +43,9 @@ for i in range(24):
         res.append((st, en))
 st = np.mean([r[0] for r in res], axis=0)
 en = np.mean([r[1] for r in res], axis=0)
+if os.environ.get('EXTRA_LAST'):      # library built with -DMI_EXTRA_LAST: the dense-side workgroups are the launch's last
+    order = np.concatenate([np.arange(len(st) - n_dense_wg, len(st)), np.arange(0, len(st) - n_dense_wg)])
+    st, en = st[order], en[order]
 for name, lo, hi in (('dense side', 0, n_dense_wg), ('long-run scan', n_dense_wg, n_dense_wg + n_long),
                      ('64-entry waves', n_dense_wg + n_long, len(st))):
     s, e = st[lo:hi], en[lo:hi]
@@ -65,6 +68,6 @@ if hasattr(lib, 'mi_debug_seg_phases'):
     print("long-run workgroups of the last step (chunk: start, scan done, heads ordered, wave-dealt heads done, end; us from launch start):")
     t0 = t[:n_dense_wg + n_long + 832, 0].min()
     for c in list(lng[:6]) + [0, 100]:
-        w = n_dense_wg + int(c)
+        w = (0 if os.environ.get('EXTRA_LAST') else n_dense_wg) + int(c)
         print("  chunk %3d: %5.2f %5.2f %5.2f %5.2f %5.2f" % (c, (t[w, 0] - t0) / 100.0, (ph[w, 0] - t0) / 100.0, (ph[w, 1] - t0) / 100.0,
                                                           (ph[w, 2] - t0) / 100.0, (t[w, 1] - t0) / 100.0))
