@@ -38,7 +38,8 @@ extern "C" {
 /* bits a kernel may OR into the device error word */
 #define MI_IDERR_RANGE 1    /* id >= rows of its table (or negative where not allowed)    */
 #define MI_IDERR_ORDER 2    /* ids of one bag not strictly increasing (repeat / disorder) */
-#define MI_IDERR_INTERNAL 4 /* a bounded device-side wait ran out (never expected)        */
+#define MI_IDERR_INTERNAL 4 /* reserved: no kernel of this library waits on another workgroup, so none raises it; the
+                              host reports any bit it does not know as an internal device error */
 #define MI_IDERR_CAPACITY 8 /* more rows for one rank pair than the exchange block holds  */
 
 /* flags for id validation */

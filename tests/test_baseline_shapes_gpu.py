@@ -3,6 +3,7 @@
   FM       26 Criteo-Kaggle tables (33.76 M rows) x dim 16, batch 8192, TensorFlow-form Adam
   DCN-v2   the same tables, d = 26*16+13 = 429 -> 448 (the 256+192 edge tile), batch 65536
   DIN      1 M items x dim 64, history 100, batch 8192
+  bags     26 tables x dim 128, batch 65536: one GPU's shapes of the row-wise sharded configuration
 
 The oracle cannot hold 33.76 M rows of parameters AND optimizer state in seconds, and does not need
 to: a step only reads the rows its ids name.  The rows named by the test's batches are copied out
@@ -258,3 +259,67 @@ def test_din_gradients_against_both_oracles_l100(dev):
               "alone %.2e); largest element %.2e / %.2e"
               % ('factored ' if factored else 'full rows', e_s, e_x, floor, rel(summed[uniq], dE), rel(summed[uniq], dEx)))
         assert e_s <= 1e-2 and e_x <= 1.1 * floor + 1e-3
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad_rowwise"])
+def test_embedding_bags_dim128_b65536_one_gpu_share(dev, opt):
+    """The embedding kernels of the sharded-table configuration at one GPU's shapes: 26 tables x dim 128, batch
+    65536 (1.7 M entries: the global radix sort and the wide-row update paths), tables cut to 26 x 400 k rows
+    (5.3 GB) so that the test allocates in seconds - the kernels' paths depend on dim, entries per table and
+    duplicates, not on the table's height.  Gather: bit-exact against indexing the table.  Sort artefacts: exact
+    against numpy's stable argsort.  Update: the oracle on the compacted rows, and no other row moves."""
+    from recommendation_amd import ops
+    T, D, B = 26, 128, 65536
+    rows = [400000] * T
+    total = sum(rows)
+    toffs_h = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    toffs = torch.from_numpy(toffs_h).to(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    W = torch.randn((total, D), generator=g, dtype=torch.float32, device=dev) * 0.05
+    W0 = W.clone()
+    ids = torch.randint(0, rows[0], (B, T), generator=g, dtype=torch.int64, device=dev)
+    ids[:, 3] = torch.randint(0, 7, (B,), generator=g, dtype=torch.int64, device=dev)      # a hot table: runs of ~9 k
+    ids[5, 7] = -1                                                                         # one padding id
+    grad = torch.randn((B, T * D), generator=g, dtype=torch.float32, device=dev) * 1e-2
+    err = ops.new_error_word(dev)
+    out = ops.embag_fwd(W, toffs, T, ids, bag_len=1, check_flags=ops.MI_CHECK_RANGE, err=err)
+    ops.check_error_word(err)
+    glob = (ids + toffs[:T].view(1, T)).clamp_(min=0)
+    want = W[glob.view(-1)].view(B, T, D)
+    want[5, 7] = 0
+    assert torch.equal(out.view(B, T, D), want)
+    plan = ops.SortedPlan(toffs, T, total, ids, bag_len=1, runs=True)
+    keys_h = (ids.cpu().numpy() + toffs_h[:T][None, :]).reshape(-1)
+    keys_h[5 * T + 7] = total                                                              # padding sorts last
+    order = np.argsort(keys_h, kind='stable')
+    srows, perm, uniq, seg = plan.host()
+    n_valid = B * T - 1
+    assert np.array_equal(srows, keys_h[order][:n_valid]) and np.array_equal(perm, order[:n_valid])
+    assert np.array_equal(uniq, np.unique(keys_h[order][:n_valid]))
+    plan2 = ops.SortedPlan(toffs, T, total, ids, bag_len=1, runs=False)
+    state = torch.full((total,), 0.1, dtype=torch.float32, device=dev)
+    lr, eps = 0.05, 1e-8
+    if opt == 'sgd':
+        ops.bwd_apply_sgd(plan2, grad, W, lr)
+    else:
+        ops.bwd_apply_adagrad_rowwise(plan2, grad, W, state, lr, eps)
+    # oracle on the touched rows: per-row gradient sums in fp64
+    touched = torch.from_numpy(uniq.astype(np.int64)).to(dev)
+    gsum = torch.zeros((total, D), dtype=torch.float64, device=dev)
+    flat_rows = torch.from_numpy(keys_h).to(dev)
+    valid = flat_rows < total
+    gsum.index_add_(0, flat_rows[valid], grad.view(B * T, D).double()[valid])
+    gs = gsum[touched]
+    w_old = W0[touched].double()
+    if opt == 'sgd':
+        w_want = w_old - lr * gs
+    else:
+        st = 0.1 + (gs * gs).mean(dim=1, keepdim=True)
+        w_want = w_old - lr * gs / (st.sqrt() + eps)
+        assert rel(state[touched].cpu().numpy(), st.view(-1).cpu().numpy()) <= 1e-5
+    assert rel(W[touched].cpu().numpy(), w_want.cpu().numpy()) <= 1e-5
+    moved = (W != W0).any(dim=1)
+    untouched = torch.ones(total, dtype=torch.bool, device=dev)
+    untouched[touched] = False
+    assert not bool((moved & untouched).any())
