@@ -397,6 +397,42 @@ def bench_dcn(args):
     return res
 
 
+def _embag_cpu_baseline(args, T, D, B, L, opt, ids_full, grad):
+    """The embedding-bag step of the numpy oracle (oracle.embedding.step_mt: gather + pooling, stable argsort,
+    segment sums, optimizer on the distinct rows - the gather formulation; a one-hot matrix of these tables is
+    infeasible) on every host core, at the SAME batch, dim, bag length and table count.  The tables are cut to
+    400 k rows each (the host cannot build 64 GB of rows in the seconds a bench run has; a row still misses the
+    CPU's caches, but the duplicates per step are those of the cut tables)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import embedding as oe
+    rc = 400000
+    cores = host_cores()
+    rng = np.random.default_rng(0)
+    toffs_c = np.arange(T + 1, dtype=np.int64) * rc
+    Wc = rng.random((T * rc, D), dtype=np.float32)
+    Wc -= np.float32(0.5)
+    Wc *= np.float32(0.1)
+    stc = np.zeros(T * rc, np.float32) if opt == 'adagrad_rowwise' else None
+    mc, vc = (np.zeros_like(Wc), np.zeros_like(Wc)) if opt == 'adam_tf' else (None, None)
+    idc = (ids_full.reshape(B, T, L) % rc).astype(np.int64)
+    out = np.empty((B, T * D), np.float32)
+    times = []
+    with ThreadPoolExecutor(cores) as pool:
+        def cpu_step():
+            oe.step_mt(Wc, stc, mc, vc, toffs_c, T, idc, grad, opt, pool, cores, lr=0.01, eps=1e-8, lr_t=1e-3, out=out)
+        for _ in range(3):
+            cpu_step()
+        t_end = time.perf_counter() + 20.0
+        while len(times) < args.cpu_steps and (len(times) < 3 or time.perf_counter() < t_end):
+            c0 = time.perf_counter()
+            cpu_step()
+            times.append(time.perf_counter() - c0)
+    return dict(value=round(B / float(np.median(times)), 1), unit='samples/s', cores=cores, kind='port',
+                sample='median of %d steps after 3 warm-up steps of the same batch (%d x %d bags of %d ids, dim %d, %s) '
+                       'through the numpy oracle (gather formulation, vectorised per table, %d threads over the tables), '
+                       'tables cut to %d rows each (%.1f GB)' % (len(times), B, T, L, D, opt, cores, rc, T * rc * D * 4 / 1e9))
+
+
 def bench_embag(args):
     """Embedding gather + sum pooling forward and the sort-based backward with the fused
     optimizer (TensorFlow-form Adam unless --opt says otherwise), on one GPU's share of the sharded-table
@@ -487,36 +523,7 @@ def bench_embag(args):
                        'traffic_source': 'quoted profiles/r0x_embag_b65536_%s_pmc.json (null when absent or another workload)' % opt,
                        'alg_bytes_per_launch': dom['alg_bytes'], 'ms_per_launch': dom['ms']}
     if not args.no_cpu_baseline:
-        from oracle import embedding as oe
-        Bc, rc = 2048, 100000
-        rng = np.random.default_rng(0)
-        toffs_c = np.arange(T + 1, dtype=np.int64) * rc
-        Wc = (rng.standard_normal((T * rc, D)) * 0.05).astype(np.float32)
-        stc = np.zeros(T * rc, np.float32)
-        mc, vc = (np.zeros_like(Wc), np.zeros_like(Wc)) if opt == 'adam_tf' else (None, None)
-        idc = rng.integers(0, rc, size=(Bc, T, L)).astype(np.int64)
-        gc = (rng.standard_normal((Bc, T * D)) * 1e-3).astype(np.float32)
-
-        def cpu_step():
-            oe.embag_fwd(Wc, toffs_c, T, idc, bag_len=L)
-            grads = oe.row_grads(toffs_c, T, idc, gc, D, bag_len=L)
-            if opt == 'adagrad_rowwise':
-                oe.apply_adagrad_rowwise(Wc, stc, grads, 0.01, 1e-8)
-            elif opt == 'sgd':
-                oe.apply_sgd(Wc, grads, 0.01)
-            else:
-                oe.apply_adam_tf(Wc, mc, vc, grads, 1e-3, 0.9, 0.999, 1e-8)
-
-        cpu_step()
-        t0, k = time.perf_counter(), 0
-        while k < args.cpu_steps and time.perf_counter() - t0 < 20.0:
-            cpu_step()
-            k += 1
-        cdt = time.perf_counter() - t0
-        res['cpu_baseline'] = dict(value=round(k * Bc / cdt, 1), unit='samples/s', cores=1, kind='port',
-                                   sample='%d steps of batch %d, same table count / dim / bag length with tables cut to '
-                                          '%d rows each (%.1f GB), through the numpy oracle (single thread)'
-                                          % (k, Bc, rc, T * rc * D * 4 / 1e9))
+        res['cpu_baseline'] = _embag_cpu_baseline(args, T, D, B, L, opt, batches[0].cpu().numpy(), grad.cpu().numpy())
     return res
 
 
@@ -641,34 +648,7 @@ def bench_sharded_embag(args):
                            'frac': round(dom['gbs'] / HBM_PEAK_GBS, 4), 'traffic': None, 'traffic_source': None,
                            'alg_bytes_per_launch': dom['alg_bytes'], 'ms_per_launch': dom['ms']}
         if not args.no_cpu_baseline:
-            from oracle import embedding as oe
-            rc = 100000
-            rng = np.random.default_rng(0)
-            toffs_c = np.arange(T + 1, dtype=np.int64) * rc
-            Wc = (rng.standard_normal((T * rc, D)) * 0.05).astype(np.float32)
-            stc = np.zeros(T * rc, np.float32)
-            idc = rng.integers(0, rc, size=(B, T, L)).astype(np.int64)
-            gc = grad.cpu().numpy()
-
-            def cpu_step():
-                oe.embag_fwd(Wc, toffs_c, T, idc, bag_len=L)
-                grads = oe.row_grads(toffs_c, T, idc, gc, D, bag_len=L)
-                if opt == 'sgd':
-                    oe.apply_sgd(Wc, grads, 0.01)
-                else:
-                    oe.apply_adagrad_rowwise(Wc, stc, grads, 0.01, 1e-8)
-
-            cpu_step()
-            times = []
-            t_end = time.perf_counter() + 20.0
-            while len(times) < args.cpu_steps and time.perf_counter() < t_end:
-                c0 = time.perf_counter()
-                cpu_step()
-                times.append(time.perf_counter() - c0)
-            res['cpu_baseline'] = dict(value=round(B / float(np.median(times)), 1), unit='samples/s', cores=1, kind='port',
-                                       sample='median of %d steps of the same batch (%d x %d bags, dim %d) on ONE rank\'s work, tables cut '
-                                              'to %d rows each, through the numpy oracle (per-bag loops, one thread)'
-                                              % (len(times), B, T, D, rc))
+            res['cpu_baseline'] = _embag_cpu_baseline(args, T, D, B, L, opt, batches[0].cpu().numpy(), grad.cpu().numpy())
     torch.distributed.barrier()
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)

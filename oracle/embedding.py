@@ -157,3 +157,51 @@ def apply_adam_tf(w, m, v, grads, lr_t, beta1, beta2, eps, dense=False):
     omb2 = float(np.float32(1.0) - np.float32(beta2))
     for r in rows:
         w[r], m[r], v[r] = adam_tf_update(w[r], m[r], v[r], grads.get(r, zero), lr_t, omb1, omb2, eps)
+
+
+def step_mt(W, state, m, v, table_offsets, T, ids, grad_out, opt, pool, workers, lr=0.01, eps=1e-8, lr_t=1e-3,
+            beta1=0.9, beta2=0.999, out=None):
+    """One embedding-bag step on the host at full speed: the same arithmetic as embag_fwd + row_grads +
+    apply_* (sum pooling, fixed-width bags, no padding ids), vectorised per table and spread over ``workers``
+    threads of ``pool`` (a table is independent of every other; numpy's gathers, sorts and reductions release
+    the interpreter lock).  Per table: forward = gather + sum over the bag; backward = stable argsort of the
+    table's ids, segment sums of the bags' gradient rows by np.add.reduceat, the optimizer on the distinct
+    rows.  This is what bench.py times as the CPU baseline of the embedding workloads; tests hold it to the
+    per-row functions above.  Returns the pooled output [B, T*D]."""
+    W = np.asarray(W)
+    ids = np.asarray(ids)
+    B = ids.shape[0]
+    L = ids.shape[2] if ids.ndim == 3 else 1
+    ids = ids.reshape(B, T, L)
+    D = W.shape[1]
+    if out is None:
+        out = np.empty((B, T * D), dtype=W.dtype)
+    omb1 = np.float32(1.0) - np.float32(beta1)
+    omb2 = np.float32(1.0) - np.float32(beta2)
+
+    def table(t):
+        base = int(table_offsets[t])
+        idt = ids[:, t, :]
+        rows = W[base + idt.reshape(-1)].reshape(B, L, D)
+        out[:, t * D:(t + 1) * D] = rows.sum(axis=1) if L > 1 else rows[:, 0, :]
+        keys = idt.reshape(-1)
+        order = np.argsort(keys, kind='stable')
+        sk = keys[order]
+        starts = np.flatnonzero(np.concatenate([[True], sk[1:] != sk[:-1]]))
+        g = grad_out[:, t * D:(t + 1) * D]
+        gsum = np.add.reduceat(g[order // L], starts, axis=0)
+        r = base + sk[starts]
+        if opt == 'sgd':
+            W[r] -= W.dtype.type(lr) * gsum
+        elif opt == 'adagrad_rowwise':
+            st = state[r] + (gsum * gsum).mean(axis=1)
+            state[r] = st
+            W[r] -= (W.dtype.type(lr) / (np.sqrt(st) + W.dtype.type(eps)))[:, None] * gsum
+        else:
+            mi = m[r] + (gsum - m[r]) * omb1
+            vi = v[r] + (gsum * gsum - v[r]) * omb2
+            m[r], v[r] = mi, vi
+            W[r] -= mi * W.dtype.type(lr_t) / (np.sqrt(vi) + W.dtype.type(eps))
+
+    list(pool.map(table, range(T))) if workers > 1 else [table(t) for t in range(T)]
+    return out

@@ -94,3 +94,40 @@ def test_threaded_fm_step_equals_the_plain_step():
         for name in ('V', 'w1', 'wd'):
             assert np.allclose(getattr(a, name), getattr(b, name), rtol=1e-6, atol=1e-9), (opt, name)
         assert abs(float(a.bias) - float(b.bias)) <= 1e-7
+
+
+def test_threaded_embedding_step_equals_the_per_row_oracle():
+    """oracle.embedding.step_mt (what bench.py times on the host cores) against the per-row functions, for the
+    three optimizers, one id per bag and multi-hot bags."""
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    from oracle import embedding as oe
+    rng = np.random.default_rng(8)
+    T, D, B = 3, 8, 50
+    rows = [40, 7, 200]
+    toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    for L in (1, 5):
+        ids = np.stack([rng.integers(0, r, size=(B, L)) for r in rows], axis=1).astype(np.int64)
+        grad = rng.standard_normal((B, T * D))
+        for opt in ('sgd', 'adagrad_rowwise', 'adam_tf'):
+            W0 = rng.standard_normal((int(toffs[-1]), D))
+            Wa, Wb = W0.copy(), W0.copy()
+            sa, sb = np.full(len(W0), 0.1), np.full(len(W0), 0.1)
+            ma, va = rng.standard_normal(W0.shape) * 0.1, rng.random(W0.shape) * 0.1
+            mb, vb = ma.copy(), va.copy()
+            want_out = oe.embag_fwd(Wa, toffs, T, ids, bag_len=L)
+            grads = oe.row_grads(toffs, T, ids, grad, D, bag_len=L)
+            if opt == 'sgd':
+                oe.apply_sgd(Wa, grads, 0.05)
+            elif opt == 'adagrad_rowwise':
+                oe.apply_adagrad_rowwise(Wa, sa, grads, 0.05, 1e-8)
+            else:
+                oe.apply_adam_tf(Wa, ma, va, grads, 1e-2, 0.9, 0.999, 1e-8)
+            with ThreadPoolExecutor(3) as pool:
+                got_out = oe.step_mt(Wb, sb, mb, vb, toffs, T, ids, grad, opt, pool, 3, lr=0.05, eps=1e-8, lr_t=1e-2)
+            assert np.allclose(got_out, want_out, rtol=1e-12, atol=1e-12)
+            assert np.allclose(Wb, Wa, rtol=1e-6, atol=1e-9), (opt, L)      # (1 - beta) is formed in fp32 by both
+            if opt == 'adagrad_rowwise':
+                assert np.allclose(sb, sa, rtol=1e-12)
+            if opt == 'adam_tf':
+                assert np.allclose(mb, ma, rtol=1e-6) and np.allclose(vb, va, rtol=1e-6)
