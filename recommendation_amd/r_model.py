@@ -138,6 +138,10 @@ class RecommendationModel(object):
         self._gen = torch.Generator(device='cpu')
         self._gen.manual_seed(0 if seed is None else int(seed))
         self._arena = torch.zeros(0, dtype=torch.float32, device=self.device)
+        self._grads = None               # flat gradient buffer, laid out like the arena
+        self._leaves = {}                # name -> autograd leaf sharing the arena's memory (its .grad a view of _grads)
+        self._leaves_of = None           # data_ptr of the arena the leaves were made for
+        self._want_grad = False
         self._slots = OrderedDict()      # name -> (offset, shape)
         self._cursor = 0                 # index of the next tf.layers.dense call
         self._toffs = {}
@@ -162,6 +166,32 @@ class RecommendationModel(object):
         n = int(np.prod(shape))
         return self._arena[off:off + n].view(shape)
 
+    def _leaf(self, name):
+        """The variable as an autograd leaf: a detached view of the arena (so the optimizer's in-place update of
+        the arena is the update of the leaf) whose .grad is a view of one flat gradient buffer - backward then
+        adds every variable's gradient straight into that buffer (one launch a variable) instead of building a
+        zero-filled full-size gradient of a shared parameter tensor per variable and adding those up."""
+        if self._leaves_of != self._arena.data_ptr() or self._grads is None or self._grads.numel() != self._arena.numel():
+            self._grads = torch.zeros_like(self._arena)
+            self._leaves = {}
+            self._leaves_of = self._arena.data_ptr()
+        leaf = self._leaves.get(name)
+        if leaf is None:
+            off, shape = self._slots[name]
+            n = int(np.prod(shape))
+            leaf = self._arena[off:off + n].view(shape).detach().requires_grad_(True)
+            leaf.grad = self._grads[off:off + n].view(shape)
+            self._leaves[name] = leaf
+        return leaf
+
+    def zero_grad(self):
+        if self._grads is not None:
+            self._grads.zero_()
+
+    def grad_arena(self):
+        """The flat gradient buffer (same layout as parameters()); filled by backward."""
+        return self._grads
+
     def _dense_vars(self, in_dim, units, first):
         """Variables of the next ``tf.layers.dense`` call (r_model.py:53-57): truncated normal
         (|x| <= 2, redrawn) for the first layer of a network, uniform [0,1) for the others,
@@ -176,7 +206,10 @@ class RecommendationModel(object):
                 k = torch.rand((in_dim, units), dtype=torch.float32, generator=self._gen)
             self._new_variable(base + '/kernel', k)
             self._new_variable(base + '/bias', torch.zeros((units,), dtype=torch.float32))
-        kernel, bias = self._view(base + '/kernel'), self._view(base + '/bias')
+        if self._want_grad and torch.is_grad_enabled():
+            kernel, bias = self._leaf(base + '/kernel'), self._leaf(base + '/bias')
+        else:
+            kernel, bias = self._view(base + '/kernel'), self._view(base + '/bias')
         if tuple(kernel.shape) != (in_dim, units):
             raise ValueError("layer %s was built for %s, now asked for %s" % (base, tuple(kernel.shape),
                                                                                (in_dim, units)))
@@ -188,7 +221,7 @@ class RecommendationModel(object):
         return OrderedDict((n, self._view(n).detach()) for n in self._slots)
 
     def parameters(self):
-        """The single flat fp32 buffer holding every variable (leaf for autograd)."""
+        """The single flat fp32 buffer holding every variable (the autograd leaves are views of it: _leaf)."""
         return self._arena
 
     def load_variables(self, values):
@@ -237,8 +270,7 @@ class RecommendationModel(object):
             # parameter buffer enters the autograd graph - creating one reallocates the buffer
             with torch.no_grad():
                 self._wire(features, units)
-        if torch.is_grad_enabled() and not self._arena.requires_grad:
-            self._arena.requires_grad_(True)
+        self._want_grad = torch.is_grad_enabled()
         return self._wire(features, units)
 
     def _wire(self, features, units):
@@ -272,7 +304,7 @@ class RecommendationModel(object):
                 'recommend_colours_2': r_c_2, 'click_colour_2': c_c_2}
 
     def network(self, inputs, units):
-        requires_grad = self._arena.requires_grad and torch.is_grad_enabled()
+        requires_grad = self._want_grad and torch.is_grad_enabled()
         if isinstance(inputs, SparseFeature):
             kernel, bias = self._dense_vars(inputs.size, units[0], first=True)
             if requires_grad:

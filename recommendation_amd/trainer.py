@@ -42,9 +42,9 @@ class AdamOptimizer(object):
         """Backward through the model, (optionally) average gradients over the ranks, update.
         Returns the new global step."""
         params = model.parameters()
-        params.grad = None
+        model.zero_grad()
         loss.backward()
-        grad = params.grad
+        grad = model.grad_arena()
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             world = torch.distributed.get_world_size(process_group)
             if world > 1:
@@ -125,7 +125,6 @@ class GraphedTrainStep(object):
             with torch.no_grad():
                 for dst, src in zip((params, optimizer.m, optimizer.v, self.sched), saved):
                     dst.copy_(src)
-            params.grad = None
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.out = self._body()
@@ -147,10 +146,10 @@ class GraphedTrainStep(object):
         acc = m.accuracy(labels, top_indices_real, m.recommend_num)
         loss = m.loss(logits=last_layer, labels=label_tensor)
         params = m.parameters()
-        params.grad = None
+        m.zero_grad()
         loss.backward()
         ops.adam_schedule_step(self.sched, opt.learning_rate, opt.beta1, opt.beta2)
-        ops.adam_tf_dense(params.detach(), opt.m, opt.v, params.grad.contiguous(), 0.0, opt.beta1, opt.beta2,
+        ops.adam_tf_dense(params.detach(), opt.m, opt.v, m.grad_arena(), 0.0, opt.beta1, opt.beta2,
                           opt.epsilon, lr_dev=self.sched)
         return acc, top_indices_real, loss.detach()
 

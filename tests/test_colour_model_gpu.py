@@ -145,7 +145,7 @@ def test_first_layer_gradient_is_the_dense_tensorflow_gradient(dev):
     opt = AdamOptimizer(learning_rate=1e-3)
     cols = tuple(torch.from_numpy(batch[k]) for k in cm._KEYS)
     train_step(m, opt, cols)
-    grad = m.parameters().grad
+    grad = m.grad_arena()
     off, shape = m._slots['dense/kernel']
     g = grad[off:off + 800].view(100, 8).cpu().numpy()
     untouched = sorted(set(range(100)) - set(batch['user'].tolist()))
