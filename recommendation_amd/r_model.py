@@ -86,7 +86,9 @@ class _EmbagDense(torch.autograd.Function):
     def backward(ctx, dy):
         dy = dy.contiguous()
         rows, dim = ctx.shape
-        plan = ops.SortedPlan(ctx.toffs, 1, rows, ctx.ids, bag_len=ctx.ids.shape[1])
+        # without run arrays: the sort is one launch (the table's entries sorted in the LDS of a CU or two) and the
+        # segmented sum finds the runs itself - two launches where the compacted-run form takes ten
+        plan = ops.SortedPlan(ctx.toffs, 1, rows, ctx.ids, bag_len=ctx.ids.shape[1], runs=False)
         return ops.bwd_dense_grad(plan, dy, dim, rows), ops.colsum(dy), None, None
 
 
