@@ -61,6 +61,8 @@ def parse_args():
                     help='single-GPU step: sort the next batch\'s ids on a side stream beside this step instead of inside '
                          'the next one (bit-identical; measured slower at B = 8192: the stream hops and the third launch '
                          'cost more than the sort they hide)')
+    ap.add_argument('--single-step-graphs', action='store_true',
+                    help='single-GPU step: one graph replay per step (default: one replay per 8 consecutive steps)')
     ap.add_argument('--ids-sample-major', action='store_true',
                     help='feed the single-GPU step ids as [B][T] only (default: also one [B] row per field)')
     ap.add_argument('--force-sharded', action='store_true',
@@ -932,13 +934,26 @@ def main():
                for j, k in enumerate(kws)]
     for i in range(max(args.warmup, 2 * len(batches) if use_graph else 0)):   # every batch's graph captured before timing
         model.train_step(*batches[i % len(batches)], **kws[i % len(batches)])
+    # a training loop that holds its next batches replays ONE graph of that many consecutive steps: the 4-5 us the
+    # device idles between two graph launches are then paid once per replay, not once per step
+    nb = len(batches)
+    multi = use_graph and not prefetch_sort and not args.single_step_graphs and B <= model._fused_max and args.steps >= nb
+    if multi:
+        for _ in range(2):
+            model.train_steps(batches, ids_tms=tms)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        kw = kws[i % len(batches)]
+    i = 0
+    while i < args.steps:
+        if multi and i % nb == 0 and i + nb <= args.steps:
+            model.train_steps(batches, ids_tms=tms)       # steps i .. i + nb - 1
+            i += nb
+            continue
+        kw = kws[i % nb]
         if sharded and (args.prefetch or (world > 1 and not args.no_prefetch)):   # next batch's ids routed and exchanged beside this step's update
-            kw = {'next_ids': batches[(i + 1) % len(batches)][0]}
-        model.train_step(*batches[i % len(batches)], **kw)
+            kw = {'next_ids': batches[(i + 1) % nb][0]}
+        model.train_step(*batches[i % nb], **kw)
+        i += 1
     barrier()
     dt = time.perf_counter() - t0
     if sharded:
@@ -959,7 +974,8 @@ def main():
                        'tables': len(rows), 'total_rows': int(sum(rows)), 'dim': args.dim, 'n_dense': 13,
                        'id_bits': args.idx_bits, 'ids': args.dist, 'seed': args.seed,
                        'id_layout': 'field-major [T][B]' if tms else 'sample-major [B][T]', 'optimizer': args.opt,
-                       'launch': 'hip graph replay' if use_graph else 'eager',
+                       'launch': ('hip graph replay, %d consecutive steps per replay' % nb if multi else
+                                  'hip graph replay, one step per replay') if use_graph else 'eager',
                        'sort': ('next batch\'s ids sorted on a side stream beside this step' if prefetch_sort
                                 else 'inside the step'),
                        'parallelism': 'single' if not sharded else 'rowwise-sharded tables x%d + replicated dense' % world},

@@ -246,3 +246,40 @@ class FactorizationMachine(object):
         if check_ids:
             ops.check_error_word(self.err, "FM ids")
         return self.loss
+
+    def train_steps(self, batches, ids_tms=None, check_ids=False):
+        """Several consecutive steps - one per (ids, dense, labels) of ``batches``, in order - replayed as ONE HIP
+        graph captured on first use for these input buffers (which must stay at the same addresses; their contents
+        may change).  Between two replays the device idles for the 4-5 us a graph launch costs; inside a replay a
+        launch follows its predecessor at once, so a training loop that has its next few batches at hand pays
+        that gap once per replay instead of once per step.  Same launches in the same order as calling
+        ``train_step`` on each batch: the same bits.  Returns the steps' mean losses as one tensor."""
+        K = len(batches)
+        shapes = set((tuple(b[0].shape), b[0].dtype) for b in batches)
+        if len(shapes) != 1:
+            raise ops.MiError("train_steps: the batches of one replay must share a shape")
+        self._buffers(batches[0][0])
+        self._prefetched = None
+        key = ('multi',) + tuple((b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr()) for b in batches) + \
+              tuple(t.data_ptr() if t is not None else 0 for t in (ids_tms or [None] * K))
+        ent = self._graphs.get(key)
+        if ent is None:
+            if self._side is None:
+                self._side = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+            losses = torch.zeros((K,), dtype=torch.float32, device=self.device)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            keep = self.loss
+            with torch.cuda.graph(g):
+                for j, (ids, dense, labels) in enumerate(batches):
+                    self.loss = losses[j:j + 1]
+                    self._step_body(ids, dense, labels, streams=self._side, ids_tm=ids_tms[j] if ids_tms else None)
+            self.loss = keep
+            ent = self._graphs[key] = (g, losses)
+        g, losses = ent
+        g.replay()
+        self.loss.copy_(losses[K - 1:K])
+        self.steps += K
+        if check_ids:
+            ops.check_error_word(self.err, "FM ids")
+        return losses

@@ -864,3 +864,31 @@ def test_fm_next_batch_sort_prefetch_leaves_the_same_bits(dev, opt, tm):
     for m in models[1:]:
         assert torch.equal(models[0].table.rec, m.table.rec)
         assert torch.equal(models[0].dp, m.dp) and torch.equal(models[0].sched, m.sched)
+
+
+def test_fm_several_steps_in_one_graph_leave_the_same_bits(dev):
+    """train_steps (one HIP graph of consecutive steps) against train_step per batch: same losses, records, dense
+    parameters and schedule, bit for bit, also when the replay is repeated with new contents in the same buffers."""
+    from recommendation_amd.fm import FactorizationMachine
+    rows = [1460, 583, 30000, 305, 24, 3, 10, 4, 18, 15, 105, 27, 2173]
+    ref = ofm.State(rows, 16, 13, seed=21, opt='adam_tf')
+    a = FactorizationMachine(rows, 16, 13, device=dev, opt='adam_tf', lr=1e-2)
+    b = FactorizationMachine(rows, 16, 13, device=dev, opt='adam_tf', lr=1e-2)
+    for m in (a, b):
+        m.load_state(ref)
+    B, K = 2048, 4
+    bufs = [tuple(torch.from_numpy(x).to(dev) for x in ofm.synthetic_batch(B, rows, 13, seed=200 + j, dist='zipf'))
+            for j in range(K)]
+    tms = [x[0].t().contiguous() for x in bufs]
+    for rnd in range(3):
+        if rnd:
+            for j in range(K):
+                for dst, src in zip(bufs[j], ofm.synthetic_batch(B, rows, 13, seed=300 + 10 * rnd + j, dist='uniform')):
+                    dst.copy_(torch.from_numpy(src))
+                tms[j].copy_(bufs[j][0].t())
+        losses = a.train_steps(bufs, ids_tms=tms).clone()
+        want = torch.cat([b.train_step(*bufs[j], ids_tm=tms[j]).clone() for j in range(K)])
+        assert torch.equal(losses, want)
+        assert torch.equal(a.loss, b.loss)
+    assert torch.equal(a.table.rec, b.table.rec) and torch.equal(a.dp, b.dp) and torch.equal(a.sched, b.sched)
+    assert a.steps == b.steps == 3 * K
