@@ -11,7 +11,9 @@
 //   digit_scan : one workgroup per digit scans that digit's per-tile counts (a contiguous
 //                row of the digit-major [radix][tiles] table) and stores the digit total
 //   scatter    : per tile, stable rank of every key among equal digits (wave-level digit
-//                matching by ballots, wave64) + digit base + tile offset -> final position.
+//                matching by ballots, wave64) + digit base + tile offset -> final position;
+//                the pairs pass through LDS in the tile's digit-sorted order so that the stores
+//                of a wave are contiguous runs.
 // Keys are uint32; a pass costs 4+4 B read and 4+4 B written per pair for scatter and
 // 4 B read for hist: 20 B per pair per pass.
 #include "common.h"
@@ -141,17 +143,32 @@ __global__ __launch_bounds__(SORT_BLOCK) void scatter_kernel(const uint32_t* __r
     loc[j] = old + before;
   }
   __syncthreads();
+  // Per digit: where the tile's entries of that digit start in the OUTPUT (digit base + this tile's offset inside
+  // the digit) and where they start in the tile's own digit-sorted order.  The entries pass through LDS in that
+  // local order and are written out by consecutive threads: entries of one digit are then neighbours both in LDS
+  // and in the output, so a wave's stores are a few contiguous runs instead of 64 scattered words.
+  __shared__ uint32_t delta[RADIX];          // output position minus local position, per digit
+  __shared__ uint32_t skey[TILE], sval[TILE];
+  uint32_t wc[PER][SORT_WAVES], lsum = 0;
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
-    // digit d: base of the digit + this tile's offset inside it, then a running base per wave
-    const int d = tid * PER + q;
-    uint32_t run = dbase + toff[q];
-    dbase += tot[q];
 #pragma unroll
     for (int i = 0; i < SORT_WAVES; ++i) {
-      const uint32_t t = cnt[i][d];
-      cnt[i][d] = run;
-      run += t;
+      wc[q][i] = cnt[i][tid * PER + q];
+      lsum += wc[q][i];
+    }
+  }
+  uint32_t lgrand;
+  uint32_t lrun = block_inclusive_scan(lsum, wsum, lgrand) - lsum;  // local exclusive prefix over the digits
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int d = tid * PER + q;
+    delta[d] = dbase + toff[q] - lrun;
+    dbase += tot[q];
+#pragma unroll
+    for (int i = 0; i < SORT_WAVES; ++i) {  // a running LOCAL base per wave
+      cnt[i][d] = lrun;
+      lrun += wc[q][i];
     }
   }
   __syncthreads();
@@ -160,9 +177,21 @@ __global__ __launch_bounds__(SORT_BLOCK) void scatter_kernel(const uint32_t* __r
     const int idx = wbase + j * MI_WAVE + lane;
     if (idx < n) {
       const uint32_t d = (key[j] >> shift) & (RADIX - 1);
-      const uint32_t pos = cnt[w][d] + loc[j];
-      keys_out[pos] = key[j];
-      vals_out[pos] = val[j];
+      const uint32_t lp = cnt[w][d] + loc[j];
+      skey[lp] = key[j];
+      sval[lp] = val[j];
+    }
+  }
+  __syncthreads();
+  const int nv = min(TILE, n - (int) blockIdx.x * TILE);  // valid entries of this tile
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const int i = j * SORT_BLOCK + tid;
+    if (i < nv) {
+      const uint32_t k = skey[i];
+      const uint32_t pos = delta[(k >> shift) & (RADIX - 1)] + (uint32_t) i;
+      keys_out[pos] = k;
+      vals_out[pos] = sval[i];
     }
   }
 }
