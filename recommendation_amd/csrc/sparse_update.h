@@ -60,7 +60,14 @@ struct PlanDev {
 
   __device__ __forceinline__ int bag_of(int p) const {
     if (!offsets) return p / bag_len;
-    if (entry_bag) return entry_bag[p];
+    if (entry_bag) {
+      // The value is consumed (an empty asm that names it) before the paths join: a load still in flight where
+      // they join would make the fixed-length path above, which loads nothing, wait there for every load the
+      // caller has outstanding - and the callers keep several heads' gradient rows in flight.
+      int e = entry_bag[p];
+      asm volatile("" : "+v"(e));
+      return e;
+    }
     int lo = 0, hi = n_bags;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
