@@ -30,7 +30,15 @@ __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict_
   float acc = 0.f;
   const float* dr = dy + row * dy_ld;
   const float* wr = W + (int64_t) k * N;
-  for (int n = 0; n < N; ++n) acc = fmaf(dr[n], wr[n], acc);
+  int n = 0;
+  for (; n + 8 <= N; n += 8) {  // sixteen loads in flight, added in column order
+    float a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = dr[n + j]; b[j] = wr[n + j]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = fmaf(a[j], b[j], acc);
+  }
+  for (; n < N; ++n) acc = fmaf(dr[n], wr[n], acc);
   dx[row * dx_ld + k] = acc;
 }
 
@@ -47,12 +55,21 @@ __global__ __launch_bounds__(256) void linear_dw_partial_kernel(const float* __r
   float* out = partial + (int64_t) blockIdx.x * total;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     float acc = 0.f;
-    if (e < K * N) {
-      const int k = e / N, n = e - k * N;
-      for (int64_t r = r0; r < r1; ++r) acc = fmaf(x[r * x_ld + k], dy[r * dy_ld + n], acc);
-    } else {
-      const int n = e - K * N;
-      for (int64_t r = r0; r < r1; ++r) acc += dy[r * dy_ld + n];
+    // rows in batches of eight: the loads of a batch are requested together (from a clamped row, masked when
+    // added) and added in row order, so a split costs four round trips, not thirty-two
+    const bool is_w = e < K * N;
+    const int k = is_w ? e / N : 0, n = is_w ? e - k * N : e - K * N;
+    for (int64_t r = r0; r < r1; r += 8) {
+      float a[8], d[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t rr = min(r + j, r1 - 1);
+        a[j] = is_w ? x[rr * x_ld + k] : 1.0f;
+        d[j] = dy[rr * dy_ld + n];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (r + j < r1) acc = is_w ? fmaf(a[j], d[j], acc) : acc + d[j];
     }
     out[e] = acc;
   }
@@ -154,18 +171,39 @@ __global__ __launch_bounds__(256) void hit_rows_kernel(const int32_t* __restrict
   hit_rows[b] = h;
 }
 
-// one workgroup per column block of 64: thread (r, n) strides rows, then a fixed LDS tree
+// One workgroup per block of 64 columns.  The 256 threads are cw columns x 256/cw row phases, cw = the block's
+// column count rounded up to a power of two (a narrow matrix keeps every lane busy: 8 columns -> 32 row phases);
+// a thread adds its rows eight loads at a time, then the row phases are added by a fixed LDS tree.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int64_t B, int N,
                                                     float* __restrict__ out) {
-  __shared__ float sh[4][64];
-  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int r = threadIdx.x >> 6;
+  __shared__ float sh[256];
+  const int n0 = blockIdx.x * 64;
+  const int cols = min(64, N - n0);
+  int cw = 1;
+  while (cw < cols) cw <<= 1;
+  const int phases = 256 / cw;
+  const int c = threadIdx.x & (cw - 1), r = threadIdx.x / cw;
+  const bool live = c < cols;
+  const float* col = x + n0 + (live ? c : 0);
   float acc = 0.f;
-  if (n < N)
-    for (int64_t b = r; b < B; b += 4) acc += x[b * ld + n];
-  sh[r][threadIdx.x & 63] = acc;
+  for (int64_t b = r; b < B; b += (int64_t) phases * 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t bb = b + (int64_t) j * phases;
+      v[j] = col[(bb < B ? bb : b) * ld];  // no branch around the load; masked below
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (b + (int64_t) j * phases < B) acc += v[j];
+  }
+  sh[threadIdx.x] = acc;
   __syncthreads();
-  if (r == 0 && n < N) out[n] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  for (int s = phases >> 1; s > 0; s >>= 1) {  // phases is a power of two
+    if (r < s) sh[threadIdx.x] += sh[threadIdx.x + s * cw];
+    __syncthreads();
+  }
+  if (r == 0 && live) out[n0 + c] = sh[c];
 }
 
 constexpr int RED_BLOCK = 1024;

@@ -250,9 +250,10 @@ def sort_pairs_u32(keys, vals, key_bits=32):
     return keys, vals
 
 
-def bwd_dense_grad(plan, grad_out, dim, total_rows, grad_ld=None):
+def bwd_dense_grad(plan, grad_out, dim, total_rows, grad_ld=None, out=None):
     grad_out = grad_out.contiguous()
-    dW = torch.empty((total_rows, dim), dtype=torch.float32, device=grad_out.device)
+    dW = out if out is not None else torch.empty((total_rows, dim), dtype=torch.float32, device=grad_out.device)
+    assert dW.is_contiguous() and tuple(dW.shape) == (total_rows, dim)
     _lib.call('mi_embag_bwd_dense_grad', plan.ref(), _p(grad_out), grad_ld or grad_out.shape[-1], dim, total_rows,
               _p(dW), _stream())
     return dW
@@ -290,15 +291,18 @@ def linear_fwd(x, W, b=None, out=None):
     return out
 
 
-def linear_bwd(x, W, dy, need_dx=True):
-    _need_cuda(x, W, dy)
+def linear_bwd(x, W, dy, need_dx=True, dW_out=None, db_out=None):
+    """dx, dW, db of y = x W + b; dW_out / db_out, when given, receive the two parameter gradients (stored, not
+    added)."""
+    _need_cuda(x, W, dy, dW_out, db_out)
     assert x.stride(-1) == 1 and dy.stride(-1) == 1 and W.is_contiguous()
     B, K = x.shape
     N = W.shape[1]
     dev = x.device
     dx = torch.empty((B, K), dtype=torch.float32, device=dev) if need_dx else None
-    dW = torch.empty((K, N), dtype=torch.float32, device=dev)
-    db = torch.empty((N,), dtype=torch.float32, device=dev)
+    dW = dW_out if dW_out is not None else torch.empty((K, N), dtype=torch.float32, device=dev)
+    db = db_out if db_out is not None else torch.empty((N,), dtype=torch.float32, device=dev)
+    assert dW.is_contiguous() and tuple(dW.shape) == (K, N) and db.is_contiguous() and db.numel() == N
     ws_bytes = _lib.load().mi_linear_bwd_workspace_bytes(B, K, N)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
     _lib.call('mi_linear_bwd', _p(x), x.stride(0), _p(W), _p(dy), dy.stride(0), _p(dx), K, _p(dW), _p(db), B, K, N,
@@ -337,11 +341,13 @@ def hit_rows(labels, preds):
     return out
 
 
-def colsum(x):
-    _need_cuda(x)
+def colsum(x, out=None):
+    _need_cuda(x, out)
     assert x.stride(-1) == 1
     B, N = x.shape
-    out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and out.numel() == N
     _lib.call('mi_colsum', _p(x), x.stride(0), B, N, _p(out), _stream())
     return out
 

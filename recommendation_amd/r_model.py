@@ -72,14 +72,38 @@ def concat(values, axis=1):
 
 
 # ----------------------------------------------------------------------------- autograd glue
+class _GradSink(object):
+    """Where a variable's gradient goes when it can simply be stored: its slice of the model's flat gradient
+    buffer, written by the backward kernel itself.  The op's backward then hands autograd no gradient for the
+    variable, which saves the temporary and the add autograd would launch per variable.  Storing equals
+    accumulating only while the slice is still zero and nothing else will add to it, so a sink allows it when
+    the variable entered exactly one op since the last finished backward (`uses`) and nothing was written to
+    the slice since it was zeroed (`dirty`); every other case takes autograd's accumulating path."""
+    __slots__ = ('view', 'uses', 'dirty')
+
+    def __init__(self, view):
+        self.view, self.uses, self.dirty = view, 0, False
+
+    def take(self):
+        """The buffer to store into, or None when the gradient has to be accumulated by autograd."""
+        direct = self.uses == 1 and not self.dirty
+        self.dirty = True
+        return self.view if direct else None
+
+
+def _take(sink):
+    return sink.take() if sink is not None else None
+
+
 class _EmbagDense(torch.autograd.Function):
     """first tf.layers.dense on a one-hot input: forward = gather+pool+bias, backward = the
     dense kernel gradient X^T dY (sorted segmented sum) and the bias gradient."""
 
     @staticmethod
-    def forward(ctx, kernel, bias, ids, toffs):
+    def forward(ctx, kernel, bias, ids, toffs, ksink=None, bsink=None):
         ctx.ids, ctx.toffs = ids, toffs
         ctx.shape = kernel.shape
+        ctx.sinks = (ksink, bsink)
         return ops.embag_fwd(kernel, toffs, 1, ids, bag_len=ids.shape[1], bias=bias)
 
     @staticmethod
@@ -89,21 +113,26 @@ class _EmbagDense(torch.autograd.Function):
         # without run arrays: the sort is one launch (the table's entries sorted in the LDS of a CU or two) and the
         # segmented sum finds the runs itself - two launches where the compacted-run form takes ten
         plan = ops.SortedPlan(ctx.toffs, 1, rows, ctx.ids, bag_len=ctx.ids.shape[1], runs=False)
-        return ops.bwd_dense_grad(plan, dy, dim, rows), ops.colsum(dy), None, None
+        gk, gb = _take(ctx.sinks[0]), _take(ctx.sinks[1])
+        dW = ops.bwd_dense_grad(plan, dy, dim, rows, out=gk)
+        db = ops.colsum(dy, out=gb)
+        return (None if gk is not None else dW), (None if gb is not None else db), None, None, None, None
 
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, kernel, bias):
+    def forward(ctx, x, kernel, bias, ksink=None, bsink=None):
         x = x.contiguous()
         ctx.save_for_backward(x, kernel)
+        ctx.sinks = (ksink, bsink)
         return ops.linear_fwd(x, kernel, bias)
 
     @staticmethod
     def backward(ctx, dy):
         x, kernel = ctx.saved_tensors
-        dx, dW, db = ops.linear_bwd(x, kernel, dy.contiguous(), need_dx=ctx.needs_input_grad[0])
-        return dx, dW, db
+        gk, gb = _take(ctx.sinks[0]), _take(ctx.sinks[1])
+        dx, dW, db = ops.linear_bwd(x, kernel, dy.contiguous(), need_dx=ctx.needs_input_grad[0], dW_out=gk, db_out=gb)
+        return dx, (None if gk is not None else dW), (None if gb is not None else db), None, None
 
 
 class _MeanSoftmaxXent(torch.autograd.Function):
@@ -142,6 +171,7 @@ class RecommendationModel(object):
         self._arena = torch.zeros(0, dtype=torch.float32, device=self.device)
         self._grads = None               # flat gradient buffer, laid out like the arena
         self._leaves = {}                # name -> autograd leaf sharing the arena's memory (its .grad a view of _grads)
+        self._sinks = {}                 # name -> _GradSink over the same view of _grads
         self._leaves_of = None           # data_ptr of the arena the leaves were made for
         self._want_grad = False
         self._slots = OrderedDict()      # name -> (offset, shape)
@@ -176,6 +206,7 @@ class RecommendationModel(object):
         if self._leaves_of != self._arena.data_ptr() or self._grads is None or self._grads.numel() != self._arena.numel():
             self._grads = torch.zeros_like(self._arena)
             self._leaves = {}
+            self._sinks = {}
             self._leaves_of = self._arena.data_ptr()
         leaf = self._leaves.get(name)
         if leaf is None:
@@ -184,11 +215,21 @@ class RecommendationModel(object):
             leaf = self._arena[off:off + n].view(shape).detach().requires_grad_(True)
             leaf.grad = self._grads[off:off + n].view(shape)
             self._leaves[name] = leaf
+            self._sinks[name] = _GradSink(leaf.grad)
         return leaf
 
     def zero_grad(self):
         if self._grads is not None:
             self._grads.zero_()
+        for sink in self._sinks.values():
+            sink.dirty = False
+
+    def backward_done(self):
+        """Tell the model that the graphs built by its forward calls so far have been backpropagated (the train
+        step does, after loss.backward()): the next forward starts counting the uses of each variable afresh.
+        Without it gradients stay correct - every op just falls back to autograd's accumulating adds."""
+        for sink in self._sinks.values():
+            sink.uses = 0
 
     def grad_arena(self):
         """The flat gradient buffer (same layout as parameters()); filled by backward."""
@@ -208,14 +249,18 @@ class RecommendationModel(object):
                 k = torch.rand((in_dim, units), dtype=torch.float32, generator=self._gen)
             self._new_variable(base + '/kernel', k)
             self._new_variable(base + '/bias', torch.zeros((units,), dtype=torch.float32))
+        sinks = (None, None)
         if self._want_grad and torch.is_grad_enabled():
             kernel, bias = self._leaf(base + '/kernel'), self._leaf(base + '/bias')
+            sinks = (self._sinks[base + '/kernel'], self._sinks[base + '/bias'])
+            for sink in sinks:
+                sink.uses += 1
         else:
             kernel, bias = self._view(base + '/kernel'), self._view(base + '/bias')
         if tuple(kernel.shape) != (in_dim, units):
             raise ValueError("layer %s was built for %s, now asked for %s" % (base, tuple(kernel.shape),
                                                                                (in_dim, units)))
-        return kernel, bias
+        return kernel, bias, sinks
 
     @property
     def variables(self):
@@ -308,18 +353,20 @@ class RecommendationModel(object):
     def network(self, inputs, units):
         requires_grad = self._want_grad and torch.is_grad_enabled()
         if isinstance(inputs, SparseFeature):
-            kernel, bias = self._dense_vars(inputs.size, units[0], first=True)
+            kernel, bias, sinks = self._dense_vars(inputs.size, units[0], first=True)
             if requires_grad:
-                layer = _EmbagDense.apply(kernel, bias, inputs.ids, self._table_offsets(inputs.size))
+                layer = _EmbagDense.apply(kernel, bias, inputs.ids, self._table_offsets(inputs.size), *sinks)
             else:
                 layer = ops.embag_fwd(kernel, self._table_offsets(inputs.size), 1, inputs.ids,
                                       bag_len=inputs.ids.shape[1], bias=bias)
         else:
-            kernel, bias = self._dense_vars(inputs.shape[1], units[0], first=True)
-            layer = _Linear.apply(inputs, kernel, bias) if requires_grad else ops.linear_fwd(inputs.contiguous(), kernel, bias)
+            kernel, bias, sinks = self._dense_vars(inputs.shape[1], units[0], first=True)
+            layer = (_Linear.apply(inputs, kernel, bias, *sinks) if requires_grad
+                     else ops.linear_fwd(inputs.contiguous(), kernel, bias))
         for i in units[1:]:
-            kernel, bias = self._dense_vars(layer.shape[1], i, first=False)
-            layer = _Linear.apply(layer, kernel, bias) if requires_grad else ops.linear_fwd(layer.contiguous(), kernel, bias)
+            kernel, bias, sinks = self._dense_vars(layer.shape[1], i, first=False)
+            layer = (_Linear.apply(layer, kernel, bias, *sinks) if requires_grad
+                     else ops.linear_fwd(layer.contiguous(), kernel, bias))
         return layer
 
     def input_to_one_hot(self, input, size):

@@ -44,6 +44,7 @@ class AdamOptimizer(object):
         params = model.parameters()
         model.zero_grad()
         loss.backward()
+        model.backward_done()
         grad = model.grad_arena()
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             world = torch.distributed.get_world_size(process_group)
@@ -148,6 +149,7 @@ class GraphedTrainStep(object):
         params = m.parameters()
         m.zero_grad()
         loss.backward()
+        m.backward_done()
         ops.adam_schedule_step(self.sched, opt.learning_rate, opt.beta1, opt.beta2)
         ops.adam_tf_dense(params.detach(), opt.m, opt.v, m.grad_arena(), 0.0, opt.beta1, opt.beta2,
                           opt.epsilon, lr_dev=self.sched)

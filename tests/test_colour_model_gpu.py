@@ -165,6 +165,48 @@ def test_first_layer_gradient_is_the_dense_tensorflow_gradient(dev):
     assert np.abs(got[moved_without_grad] - params['dense/kernel'][moved_without_grad]).min() > 1e-4
 
 
+def test_gradients_stored_by_the_backward_kernels_equal_autograd_accumulation(dev):
+    """A variable used by one op of the step has its gradient stored straight into the flat gradient buffer;
+    every other case (a second forward before the backward, two losses over the same variables, a missing
+    zero_grad) goes through autograd's adds.  All of them must give the same bits."""
+    params = oracle_params(4)
+    batch = cm.synthetic_batch(64, seed=4)
+    d = to_dev(batch, dev)
+    feats = {k: d[k] for k in d if k != 'label'}
+
+    def loss_of(m):
+        label = m.input_to_one_hot_plus(d['label'], m.colour_count)
+        return m.loss(logits=m.forward(m.features(feats)), labels=label)
+
+    m = model_with(params, dev)
+    loss = loss_of(m)
+    m.zero_grad()
+    loss.backward()
+    m.backward_done()
+    assert all(s.dirty and s.uses == 0 for s in m._sinks.values()) and len(m._sinks) == 22
+    stored = m.grad_arena().clone()
+    assert stored.abs().sum().item() > 0
+
+    loss_of(m)                       # a graph that is never backpropagated: every variable now has two uses
+    loss = loss_of(m)
+    m.zero_grad()
+    loss.backward()                  # -> autograd adds into the zeroed buffer
+    assert all(s.uses == 2 for s in m._sinks.values())
+    assert torch.equal(m.grad_arena(), stored)
+    m.backward_done()
+
+    total = loss_of(m) + loss_of(m)  # both graphs backpropagated at once
+    m.zero_grad()
+    total.backward()
+    m.backward_done()
+    assert torch.equal(m.grad_arena(), 2 * stored)
+
+    loss = loss_of(m)                # no zero_grad: the slices are dirty, so this step's gradients are added
+    loss.backward()
+    m.backward_done()
+    assert torch.equal(m.grad_arena(), 2 * stored + stored)
+
+
 def test_train_loop_from_files_follows_the_oracle_trajectory(dev, tmp_path):
     """Mirror of local_train_utils.train on synthetic files: labels come from a fixed random
     'teacher' model thresholded at 0.3 (as data.py:156-159, 196-236 do).  40 steps from the same
