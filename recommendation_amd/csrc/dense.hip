@@ -16,39 +16,49 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   const int n = (int) (g - row * N);
   float acc = 0.f;
   const float* xr = x + row * x_ld;
-  for (int k = 0; k < K; ++k) acc = fmaf(xr[k], W[(int64_t) k * N + n], acc);
+  const float* wc = W + n;
+  int k = 0;
+  for (; k + 8 <= K; k += 8) {  // sixteen loads in flight, added in row order
+    float a[8], w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = xr[k + j]; w[j] = wc[(int64_t) (k + j) * N]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = fmaf(a[j], w[j], acc);
+  }
+  for (; k < K; ++k) acc = fmaf(xr[k], wc[(int64_t) k * N], acc);
   y[row * y_ld + n] = acc + (b ? b[n] : 0.f);
 }
 
-__global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ W, const float* __restrict__ dy,
-                                                       int64_t dy_ld, float* __restrict__ dx, int64_t dx_ld, int64_t B,
-                                                       int K, int N) {
-  const int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= B * K) return;
-  const int64_t row = g / K;
-  const int k = (int) (g - row * K);
-  float acc = 0.f;
-  const float* dr = dy + row * dy_ld;
-  const float* wr = W + (int64_t) k * N;
-  int n = 0;
-  for (; n + 8 <= N; n += 8) {  // sixteen loads in flight, added in column order
-    float a[8], b[8];
+constexpr int ROWS_PER_SPLIT = 16;
+
+// Backward of y = x W + b in one launch of two kinds of workgroup (they share nothing):
+//   [0, splits)        partial[s][k*N+n] = sum over the split's rows of x[r][k]*dy[r][n]; partial[s][K*N+n] = sum dy[r][n]
+//   [splits, gridDim)  dx[r][k] = sum_n dy[r][n] W[k][n], one thread per element (only when dx is wanted)
+__global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict__ x, int64_t x_ld,
+                                                        const float* __restrict__ W, const float* __restrict__ dy,
+                                                        int64_t dy_ld, float* __restrict__ dx, int64_t dx_ld,
+                                                        float* __restrict__ partial, int64_t B, int K, int N,
+                                                        int splits, int rows_per_split) {
+  if ((int) blockIdx.x >= splits) {
+    const int64_t g = (int64_t) (blockIdx.x - splits) * blockDim.x + threadIdx.x;
+    if (g >= B * K) return;
+    const int64_t row = g / K;
+    const int k = (int) (g - row * K);
+    float acc = 0.f;
+    const float* dr = dy + row * dy_ld;
+    const float* wr = W + (int64_t) k * N;
+    int n = 0;
+    for (; n + 8 <= N; n += 8) {  // sixteen loads in flight, added in column order
+      float a[8], b[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { a[j] = dr[n + j]; b[j] = wr[n + j]; }
+      for (int j = 0; j < 8; ++j) { a[j] = dr[n + j]; b[j] = wr[n + j]; }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc = fmaf(a[j], b[j], acc);
+      for (int j = 0; j < 8; ++j) acc = fmaf(a[j], b[j], acc);
+    }
+    for (; n < N; ++n) acc = fmaf(dr[n], wr[n], acc);
+    dx[row * dx_ld + k] = acc;
+    return;
   }
-  for (; n < N; ++n) acc = fmaf(dr[n], wr[n], acc);
-  dx[row * dx_ld + k] = acc;
-}
-
-constexpr int ROWS_PER_SPLIT = 32;
-
-// partial[s][k*N+n] = sum over the split's rows of x[r][k]*dy[r][n]; partial[s][K*N+n] = sum dy[r][n]
-__global__ __launch_bounds__(256) void linear_dw_partial_kernel(const float* __restrict__ x, int64_t x_ld,
-                                                               const float* __restrict__ dy, int64_t dy_ld,
-                                                               float* __restrict__ partial, int64_t B, int K, int N,
-                                                               int rows_per_split) {
   const int64_t r0 = (int64_t) blockIdx.x * rows_per_split;
   const int64_t r1 = min(r0 + (int64_t) rows_per_split, B);
   const int total = K * N + N;
@@ -56,7 +66,7 @@ __global__ __launch_bounds__(256) void linear_dw_partial_kernel(const float* __r
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     float acc = 0.f;
     // rows in batches of eight: the loads of a batch are requested together (from a clamped row, masked when
-    // added) and added in row order, so a split costs four round trips, not thirty-two
+    // added) and added in row order, so a split of sixteen rows costs two round trips
     const bool is_w = e < K * N;
     const int k = is_w ? e / N : 0, n = is_w ? e - k * N : e - K * N;
     for (int64_t r = r0; r < r1; r += 8) {
@@ -269,12 +279,10 @@ extern "C" int mi_linear_bwd(const float* x, int64_t x_ld, const float* W, const
     mi_set_error("mi_linear_bwd: workspace %zu < %zu", workspace_bytes, mi_linear_bwd_workspace_bytes(B, K, N));
     return MI_ERR_WORKSPACE;
   }
-  if (dx)
-    hipLaunchKernelGGL(linear_dx_kernel, dim3((unsigned) mi_cdiv(B * K, 256)), dim3(256), 0, s, W, dy, dy_ld, dx, dx_ld,
-                       B, K, N);
   const int splits = splits_for(B);
-  hipLaunchKernelGGL(linear_dw_partial_kernel, dim3(splits), dim3(256), 0, s, x, x_ld, dy, dy_ld, (float*) workspace, B,
-                     K, N, ROWS_PER_SPLIT);
+  const unsigned dx_blocks = dx ? (unsigned) mi_cdiv(B * K, 256) : 0u;
+  hipLaunchKernelGGL(linear_bwd_kernel, dim3((unsigned) splits + dx_blocks), dim3(256), 0, s, x, x_ld, W, dy, dy_ld, dx,
+                     dx_ld, (float*) workspace, B, K, N, splits, ROWS_PER_SPLIT);
   hipLaunchKernelGGL(linear_dw_final_kernel, dim3((unsigned) mi_cdiv(K * N + N, 256)), dim3(256), 0, s,
                      (const float*) workspace, splits, K, N, dW, db);
   MI_LAUNCH_CHECK();
