@@ -89,6 +89,26 @@ int mi_validate_ids(const int64_t* table_offsets, int T, const void* indices, in
                     const int64_t* offsets, int bag_len, int64_t n_bags, int check_flags,
                     int32_t* err, void* stream);
 
+/* Several id columns at once.  The reference encodes six features and the label with one
+ * sparse_to_dense each (r_model.py:42-51 -> :60-96) and joins the encodings of a recommended list and its
+ * clicked colour with tf.concat (r_model.py:34-37); on the device each of those is a launch of a few hundred
+ * threads, so the checks of up to MI_MAX_ID_COLUMNS columns share one launch and the concatenation's id matrix
+ * is written by one.  A column holds n_bags fixed-length bags of ids of ONE table of `rows` rows. */
+#define MI_MAX_ID_COLUMNS 8
+typedef struct mi_id_column {
+  const void* ids;     /* [n_bags][bag_len], int32 or int64 (the call's idx_bits) */
+  int64_t n_bags;
+  int64_t rows;        /* size of the column's table (the one-hot width) */
+  int32_t bag_len;
+  int32_t check_flags; /* MI_CHECK_*; unused by the concatenation */
+} mi_id_column;
+/* mi_validate_ids for every column (same rules, same error word). */
+int mi_validate_id_columns(const mi_id_column* cols, int n_cols, int idx_bits, int32_t* err, void* stream);
+/* out[b] = [ids of column 0 | ids of column 1 + rows of column 0 | ...]: the ids of tf.concat(axis=1) of the
+ * columns' one-hot / n-hot matrices (ids < 0, "no entry", stay as they are); every column has B bags; out is
+ * [B][sum of bag_len] of the same integer type. */
+int mi_concat_id_columns(const mi_id_column* cols, int n_cols, int idx_bits, int64_t B, void* out, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Sparse backward, step 1: deterministic sort by (table,row).
  * Entry p (position in `indices`) gets key = table_offsets[t] + id (a global row, uint32;

@@ -36,6 +36,12 @@ class BwdPlan(Structure):
     ]
 
 
+class IdColumn(Structure):
+    """struct mi_id_column"""
+    _fields_ = [('ids', c_void_p), ('n_bags', c_int64), ('rows', c_int64), ('bag_len', c_int32),
+                ('check_flags', c_int32)]
+
+
 class FmTable(Structure):
     """struct mi_fm_table"""
     _fields_ = [('rec', c_void_p), ('stride', c_int64), ('dim', c_int), ('off_w1', c_int), ('off_vs0', c_int),
@@ -57,6 +63,8 @@ _SIGNATURES = {
                              c_int64, P, P]),
     'mi_onehot_dense': (c_int, [P, c_int, c_int, c_int64, c_int, c_int, P, P, P]),
     'mi_validate_ids': (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P, P]),
+    'mi_validate_id_columns': (c_int, [P, c_int, c_int, P, P]),
+    'mi_concat_id_columns': (c_int, [P, c_int, c_int, c_int64, P, P]),
     'mi_embag_bag_info': (c_int, [P, c_int, P, c_int, P, c_int, c_int64, P, P, P]),
     'mi_embag_bwd_workspace_bytes': (c_size_t, [c_int64]),
     'mi_embag_bwd_prepare': (c_int, [P, c_int, c_int64, P, c_int, P, c_int, c_int64, c_int64, P, P, P, P, P,

@@ -385,6 +385,54 @@ __global__ __launch_bounds__(256) void validate_kernel(const int64_t* __restrict
   if (bad) atomicOr(err, bad);
 }
 
+// Several id columns in one launch (blockIdx.y = column): the checks of validate_kernel for columns that each
+// hold fixed-length bags of ids of one table, and the id matrix of their concatenation.
+struct IdColumns {
+  mi_id_column c[MI_MAX_ID_COLUMNS];
+  int n;
+};
+
+template <typename IDX>
+__global__ __launch_bounds__(256) void validate_columns_kernel(IdColumns cols, int32_t* __restrict__ err) {
+  const mi_id_column col = cols.c[blockIdx.y];
+  const int64_t bag = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (bag >= col.n_bags) return;
+  int bad = 0;
+  int64_t prev = -1;
+  for (int j = 0; j < col.bag_len; ++j) {
+    const int64_t id = mi_ld_id<IDX>(col.ids, bag * col.bag_len + j);
+    if (id < 0) {
+      if (col.check_flags & MI_CHECK_NONNEG) bad |= MI_IDERR_RANGE;
+      continue;
+    }
+    if (id >= col.rows && (col.check_flags & MI_CHECK_RANGE)) bad |= MI_IDERR_RANGE;
+    if (col.check_flags & MI_CHECK_INCREASING) {
+      if (id <= prev) bad |= MI_IDERR_ORDER;
+      prev = id;
+    }
+  }
+  if (bad) atomicOr(err, bad);
+}
+
+// out[b] = [ ids of column 0 | ids of column 1 + rows of column 0 | ... ], negative ids (no entry) kept as they are
+template <typename IDX>
+__global__ __launch_bounds__(256) void concat_columns_kernel(IdColumns cols, int64_t B, int width,
+                                                            IDX* __restrict__ out) {
+  const int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B * width) return;
+  const int64_t b = g / width;
+  int j = (int) (g - b * width);
+  int64_t base = 0;
+  int i = 0;
+  while (i + 1 < cols.n && j >= cols.c[i].bag_len) {  // at most MI_MAX_ID_COLUMNS steps
+    j -= cols.c[i].bag_len;
+    base += cols.c[i].rows;
+    ++i;
+  }
+  const int64_t id = mi_ld_id<IDX>(cols.c[i].ids, b * cols.c[i].bag_len + j);
+  out[g] = (IDX) (id >= 0 ? id + base : id);
+}
+
 // One wave per bag: lanes stride over the bag's ids (coalesced), count the valid ones with a wave reduction and
 // note the bag against each position.
 template <typename IDX>
@@ -562,6 +610,66 @@ extern "C" int mi_validate_ids(const int64_t* table_offsets, int T, const void* 
   else
     hipLaunchKernelGGL(validate_kernel<int64_t>, dim3(grid), dim3(256), 0, s, table_offsets, T, indices, offsets,
                        bag_len, (int) n_bags, check_flags, err);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+namespace {
+int pack_columns(const mi_id_column* cols, int n_cols, int idx_bits, const char* who, IdColumns* out) {
+  MI_REQUIRE(cols && n_cols >= 1 && n_cols <= MI_MAX_ID_COLUMNS, "%s: 1..%d columns, got %d", who, MI_MAX_ID_COLUMNS,
+             n_cols);
+  MI_REQUIRE(idx_bits == 32 || idx_bits == 64, "%s: idx_bits must be 32 or 64", who);
+  out->n = n_cols;
+  for (int i = 0; i < n_cols; ++i) {
+    MI_REQUIRE(cols[i].ids || cols[i].n_bags == 0, "%s: column %d has no ids", who, i);
+    MI_REQUIRE(cols[i].n_bags >= 0 && cols[i].n_bags < (int64_t) 1 << 31 && cols[i].bag_len >= 1 && cols[i].rows >= 1,
+               "%s: column %d: n_bags / bag_len / rows out of range", who, i);
+    out->c[i] = cols[i];
+  }
+  return MI_OK;
+}
+}  // namespace
+
+extern "C" int mi_validate_id_columns(const mi_id_column* cols, int n_cols, int idx_bits, int32_t* err, void* stream) {
+  const char* who = "mi_validate_id_columns";
+  IdColumns k;
+  int rc = pack_columns(cols, n_cols, idx_bits, who, &k);
+  if (rc) return rc;
+  MI_REQUIRE(err, "%s: null error word", who);
+  int64_t most = 0;
+  for (int i = 0; i < n_cols; ++i) most = cols[i].n_bags > most ? cols[i].n_bags : most;
+  if (most == 0) return MI_OK;
+  const dim3 grid((unsigned) mi_cdiv(most, 256), (unsigned) n_cols);
+  hipStream_t s = (hipStream_t) stream;
+  if (idx_bits == 32)
+    hipLaunchKernelGGL(validate_columns_kernel<int32_t>, grid, dim3(256), 0, s, k, err);
+  else
+    hipLaunchKernelGGL(validate_columns_kernel<int64_t>, grid, dim3(256), 0, s, k, err);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_concat_id_columns(const mi_id_column* cols, int n_cols, int idx_bits, int64_t B, void* out,
+                                    void* stream) {
+  const char* who = "mi_concat_id_columns";
+  IdColumns k;
+  int rc = pack_columns(cols, n_cols, idx_bits, who, &k);
+  if (rc) return rc;
+  MI_REQUIRE(B >= 0 && B < (int64_t) 1 << 31, "%s: B out of range", who);
+  int64_t width = 0;
+  for (int i = 0; i < n_cols; ++i) {
+    MI_REQUIRE(cols[i].n_bags == B, "%s: column %d has %lld bags, not B = %lld", who, i, (long long) cols[i].n_bags,
+               (long long) B);
+    width += cols[i].bag_len;
+  }
+  if (B == 0) return MI_OK;
+  MI_REQUIRE(out && width < (int64_t) 1 << 20, "%s: null output / width out of range", who);
+  const unsigned grid = (unsigned) mi_cdiv(B * width, 256);
+  hipStream_t s = (hipStream_t) stream;
+  if (idx_bits == 32)
+    hipLaunchKernelGGL(concat_columns_kernel<int32_t>, dim3(grid), dim3(256), 0, s, k, B, (int) width, (int32_t*) out);
+  else
+    hipLaunchKernelGGL(concat_columns_kernel<int64_t>, dim3(grid), dim3(256), 0, s, k, B, (int) width, (int64_t*) out);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -141,6 +141,43 @@ def validate_ids(toffs, T, indices, check_flags, err, offsets=None, bag_len=None
               _p(err), _stream())
 
 
+MI_MAX_ID_COLUMNS = 8
+
+
+def _id_columns(columns):
+    """[(ids [B, L], table size, check flags)] -> (array of struct mi_id_column, idx_bits, tensors kept alive)."""
+    if not 1 <= len(columns) <= MI_MAX_ID_COLUMNS:
+        raise MiError("1..%d id columns, got %d" % (MI_MAX_ID_COLUMNS, len(columns)))
+    keep = [ids.contiguous() for ids, _, _ in columns]
+    _need_cuda(*keep)
+    bits = _idx_bits(keep[0])
+    if any(_idx_bits(t) != bits for t in keep):
+        raise MiError("the id columns of one call must share an integer type")
+    arr = (_lib.IdColumn * len(columns))()
+    for c, t, (_, size, flags) in zip(arr, keep, columns):
+        bag_len = t.shape[-1] if t.dim() > 1 else 1
+        c.ids, c.n_bags, c.rows, c.bag_len, c.check_flags = t.data_ptr(), t.numel() // max(bag_len, 1), size, bag_len, flags
+    return arr, bits, keep
+
+
+def validate_id_columns(columns, err):
+    """validate_ids for several columns [(ids, table size, check flags)] in one launch."""
+    arr, bits, keep = _id_columns(columns)
+    _need_cuda(err)
+    _lib.call('mi_validate_id_columns', arr, len(columns), bits, _p(err), _stream())
+
+
+def concat_id_columns(columns):
+    """Ids of tf.concat(axis=1) of one-hot / n-hot matrices given as [(ids [B, L_i], table size_i)]: column i's ids
+    shifted by the sizes before it (ids < 0 kept), one launch."""
+    arr, bits, keep = _id_columns([(ids, size, 0) for ids, size in columns])
+    B = keep[0].shape[0]
+    width = sum(int(c.bag_len) for c in arr)
+    out = torch.empty((B, width), dtype=keep[0].dtype, device=keep[0].device)
+    _lib.call('mi_concat_id_columns', arr, len(columns), bits, B, _p(out), _stream())
+    return out
+
+
 # ----------------------------------------------------------------------------- sparse backward
 class SortedPlan(object):
     """Device artefacts of ``mi_embag_bwd_prepare`` plus the struct the apply calls take."""

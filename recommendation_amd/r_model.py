@@ -55,6 +55,8 @@ class SparseFeature(object):
     @staticmethod
     def concat(parts):
         """tf.concat(..., axis=1) of one-hot matrices == ids shifted by the widths before them."""
+        if 1 < len(parts) <= ops.MI_MAX_ID_COLUMNS and len(set(p.ids.dtype for p in parts)) == 1:
+            return SparseFeature(ops.concat_id_columns([(p.ids, p.size) for p in parts]), sum(p.size for p in parts))
         ids, base = [], 0
         for p in parts:
             ids.append(torch.where(p.ids >= 0, p.ids + base, p.ids) if base else p.ids)
@@ -178,6 +180,7 @@ class RecommendationModel(object):
         self._cursor = 0                 # index of the next tf.layers.dense call
         self._toffs = {}
         self._err = None
+        self._pending_checks = None      # id columns collected by features() for one fused check
 
     # -- variables --------------------------------------------------------------------------
     @staticmethod
@@ -300,7 +303,21 @@ class RecommendationModel(object):
             if self._in_graph:
                 raise RuntimeError("the id error word must exist before a step is captured")
             self._err = ops.new_error_word(self.device)
+        if self._pending_checks is not None:        # inside features(): all its columns are checked by one launch
+            self._pending_checks.append((ids, size, flags))
+            return
         ops.validate_ids(self._table_offsets(size), 1, ids, flags, self._err, bag_len=ids.shape[-1] if ids.dim() > 1 else 1)
+
+    def _flush_checks(self):
+        checks, self._pending_checks = self._pending_checks, None
+        if not checks:
+            return
+        if len(set(c[0].dtype for c in checks)) == 1 and len(checks) <= ops.MI_MAX_ID_COLUMNS:
+            ops.validate_id_columns(checks, self._err)
+        else:
+            for ids, size, flags in checks:
+                ops.validate_ids(self._table_offsets(size), 1, ids, flags, self._err,
+                                 bag_len=ids.shape[-1] if ids.dim() > 1 else 1)
 
     def check_errors(self):
         """Raise InvalidArgumentError if any id seen since the last check was invalid.  Inside a captured step
@@ -334,12 +351,18 @@ class RecommendationModel(object):
         return last_layer
 
     def features(self, features):
-        user_fs = self.input_to_one_hot(features['user'], self.user_count)
-        country_fs = self.input_to_one_hot(features['country'], self.country_count)
-        r_c_1 = self.input_to_n_hot(features['recommend_colours_1'], self.colour_count)
-        c_c_1 = self.input_to_one_hot_plus(features['click_colour_1'], self.colour_count)
-        r_c_2 = self.input_to_n_hot(features['recommend_colours_2'], self.colour_count)
-        c_c_2 = self.input_to_one_hot_plus(features['click_colour_2'], self.colour_count)
+        self._pending_checks = [] if self.validate else None
+        try:
+            user_fs = self.input_to_one_hot(features['user'], self.user_count)
+            country_fs = self.input_to_one_hot(features['country'], self.country_count)
+            r_c_1 = self.input_to_n_hot(features['recommend_colours_1'], self.colour_count)
+            c_c_1 = self.input_to_one_hot_plus(features['click_colour_1'], self.colour_count)
+            r_c_2 = self.input_to_n_hot(features['recommend_colours_2'], self.colour_count)
+            c_c_2 = self.input_to_one_hot_plus(features['click_colour_2'], self.colour_count)
+        except Exception:
+            self._pending_checks = None
+            raise
+        self._flush_checks()
         # The error word is read (a host-device synchronisation) every `check_every` calls: 1 reports a
         # bad id in the call that fed it, as session.run does; a training loop that can live with hearing
         # of it a few steps later (the bad ids are never dereferenced meanwhile) sets it higher and calls

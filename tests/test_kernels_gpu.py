@@ -123,6 +123,58 @@ def test_empty_batch_is_a_no_op(dev):
     assert out.shape == (0, 8)
 
 
+@pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
+def test_id_columns_checked_and_concatenated_in_one_launch_each(dev, dtype):
+    """mi_validate_id_columns == mi_validate_ids column by column (same error bits, one bad column at a time);
+    mi_concat_id_columns == the shifted-id concatenation of the one-hot widths, negative ids kept."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(11)
+    B = 777
+    R, NN, RI = ops.MI_CHECK_RANGE, ops.MI_CHECK_NONNEG, ops.MI_CHECK_INCREASING
+
+    def fresh():
+        user = rng.integers(0, 100, (B, 1))
+        rec = np.sort(rng.permuted(np.tile(np.arange(128), (B, 1)), axis=1)[:, :6], axis=1)
+        click = rng.integers(-1, 128, (B, 1))
+        return [user, rec, click]
+
+    specs = [(100, R | NN), (128, R | NN | RI), (128, R)]
+
+    def bits(cols, fused):
+        err = ops.new_error_word(dev)
+        ts = [(torch.from_numpy(c).to(dev).to(dtype), size, fl) for c, (size, fl) in zip(cols, specs)]
+        if fused:
+            ops.validate_id_columns(ts, err)
+        else:
+            for t, size, fl in ts:
+                ops.validate_ids(ops.table_offsets([size], dev), 1, t, fl, err)
+        return int(err.item())
+
+    good = fresh()
+    assert bits(good, True) == 0 == bits(good, False)
+    cases = []
+    c = fresh(); c[0][5, 0] = 100; cases.append(c)          # user out of range
+    c = fresh(); c[0][0, 0] = -1; cases.append(c)           # one-hot must be non-negative
+    c = fresh(); c[1][B - 1, 3] = c[1][B - 1, 2]; cases.append(c)   # repeated id in an n-hot row
+    c = fresh(); c[1][7, :2] = c[1][7, :2][::-1]; cases.append(c)   # disorder
+    c = fresh(); c[2][B // 2, 0] = 128; cases.append(c)     # padding column: -1 fine, 128 not
+    c = fresh(); c[2][3, 0] = -7; cases.append(c)           # any negative id is "no entry" there
+    want = [ops.MI_IDERR_RANGE, ops.MI_IDERR_RANGE, ops.MI_IDERR_ORDER, ops.MI_IDERR_ORDER, ops.MI_IDERR_RANGE, 0]
+    for c, w in zip(cases, want):
+        assert bits(c, True) == bits(c, False) == w
+
+    parts = [(torch.from_numpy(c).to(dev).to(dtype), size) for c, (size, _) in zip(good, specs)]
+    parts[2][0][4, 0] = -1
+    got = ops.concat_id_columns(parts)
+    base, cols = 0, []
+    for t, size in parts:
+        cols.append(torch.where(t >= 0, t + base, t))
+        base += size
+    assert got.dtype == dtype and torch.equal(got, torch.cat(cols, dim=1))
+    with pytest.raises(ops.MiError):
+        ops.concat_id_columns([(parts[0][0], 100), (parts[1][0].to(torch.int64 if dtype == torch.int32 else torch.int32), 128)])
+
+
 def test_validation_reports_and_never_dereferences_bad_ids(dev):
     from recommendation_amd import ops
     w = torch.ones((10, 4), device=dev)
