@@ -766,7 +766,7 @@ def bench_colour(args):
     # bound by the launches of a 5,910-parameter model
     nbytes = B * (16 * 4 + 124 * 4 + 2 * 128 * 4) + 3 * 2 * 5910 * 4
     ms = dt / args.steps * 1e3
-    res['roofline'] = {'kernel': 'whole step (about 73 launches of a 5,910-parameter model: launch-bound)', 'bound': 'hbm',
+    res['roofline'] = {'kernel': 'whole step (about 70 launches of a 5,910-parameter model: launch-bound)', 'bound': 'hbm',
                        'achieved': round(nbytes / ms / 1e6, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 6), 'traffic': None, 'traffic_source': None,
                        'alg_bytes_per_launch': nbytes, 'ms_per_launch': round(ms, 5)}

@@ -288,7 +288,9 @@ def sort_pairs_u32(keys, vals, key_bits=32):
 
 
 def bwd_dense_grad(plan, grad_out, dim, total_rows, grad_ld=None, out=None):
-    grad_out = grad_out.contiguous()
+    if grad_ld is None or grad_out.stride(-1) != 1:
+        grad_out = grad_out.contiguous()
+        grad_ld = None
     dW = out if out is not None else torch.empty((total_rows, dim), dtype=torch.float32, device=grad_out.device)
     assert dW.is_contiguous() and tuple(dW.shape) == (total_rows, dim)
     _lib.call('mi_embag_bwd_dense_grad', plan.ref(), _p(grad_out), grad_ld or grad_out.shape[-1], dim, total_rows,

@@ -110,13 +110,14 @@ class _EmbagDense(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        dy = dy.contiguous()
+        if dy.stride(-1) != 1:
+            dy = dy.contiguous()          # a column slice of a wider gradient is read in place (row stride = its ld)
         rows, dim = ctx.shape
         # without run arrays: the sort is one launch (the table's entries sorted in the LDS of a CU or two) and the
         # segmented sum finds the runs itself - two launches where the compacted-run form takes ten
         plan = ops.SortedPlan(ctx.toffs, 1, rows, ctx.ids, bag_len=ctx.ids.shape[1], runs=False)
         gk, gb = _take(ctx.sinks[0]), _take(ctx.sinks[1])
-        dW = ops.bwd_dense_grad(plan, dy, dim, rows, out=gk)
+        dW = ops.bwd_dense_grad(plan, dy, dim, rows, grad_ld=dy.stride(0), out=gk)
         db = ops.colsum(dy, out=gb)
         return (None if gk is not None else dW), (None if gb is not None else db), None, None, None, None
 
@@ -133,7 +134,9 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x, kernel = ctx.saved_tensors
         gk, gb = _take(ctx.sinks[0]), _take(ctx.sinks[1])
-        dx, dW, db = ops.linear_bwd(x, kernel, dy.contiguous(), need_dx=ctx.needs_input_grad[0], dW_out=gk, db_out=gb)
+        if dy.stride(-1) != 1:
+            dy = dy.contiguous()
+        dx, dW, db = ops.linear_bwd(x, kernel, dy, need_dx=ctx.needs_input_grad[0], dW_out=gk, db_out=gb)
         return dx, (None if gk is not None else dW), (None if gb is not None else db), None, None
 
 
