@@ -206,9 +206,10 @@ class RecommendationModel(object):
 
     def _leaf(self, name):
         """The variable as an autograd leaf: a detached view of the arena (so the optimizer's in-place update of
-        the arena is the update of the leaf) whose .grad is a view of one flat gradient buffer - backward then
-        adds every variable's gradient straight into that buffer (one launch a variable) instead of building a
-        zero-filled full-size gradient of a shared parameter tensor per variable and adding those up."""
+        the arena is the update of the leaf) whose .grad is a view of one flat gradient buffer - the backward
+        kernels store each variable's gradient straight into its slice (see _GradSink; autograd adds it there in
+        the cases that need accumulation) instead of building a zero-filled full-size gradient of a shared
+        parameter tensor per variable and adding those up."""
         if self._leaves_of != self._arena.data_ptr() or self._grads is None or self._grads.numel() != self._arena.numel():
             self._grads = torch.zeros_like(self._arena)
             self._leaves = {}

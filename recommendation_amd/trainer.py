@@ -80,7 +80,7 @@ def train_step(model, optimizer, columns, process_group=None):
 
 class GraphedTrainStep(object):
     """``train_step`` for a fixed batch size captured ONCE as a HIP graph and replayed: the colour model's
-    step is ~150 launches of a 5,910-parameter model (encoder checks, 11 layers forward and backward through
+    step is ~70 launches of a 5,910-parameter model (encoder checks, 11 layers forward and backward through
     autograd, heads, Adam), each a few microseconds of device work behind tens of microseconds of Python and
     launch overhead, so the eager step is bound by the host.  Replaying the captured launches removes that;
     the arithmetic is the same kernels in the same order, so results equal the eager step's bit for bit.
