@@ -55,6 +55,8 @@ def parse_args():
                          'the default with more than one rank (measured slower at world size 1: the extra stream hops cost more '
                          'than the exchange they hide)')
     ap.add_argument('--no-prefetch', action='store_true', help='sharded path with several ranks: no next-batch id exchange beside the update')
+    ap.add_argument('--comm', choices=['torch', 'rccl'], default='torch',
+                    help="sharded FM path: collectives through torch.distributed (default) or the library's own RCCL entry points")
     ap.add_argument('--din-full-rows', action='store_true',
                     help='DIN: materialise the full [q | k | q-k | q*k] rows instead of the factored first layer')
     ap.add_argument('--prefetch-sort', action='store_true',
@@ -913,8 +915,11 @@ def main():
         from recommendation_amd.fm import FactorizationMachine
         model = FactorizationMachine(rows, args.dim, 13, device=dev, opt=args.opt, lr=1e-3, seed=0)
     else:
-        from recommendation_amd.sharded import ShardedFactorizationMachine
-        model = ShardedFactorizationMachine(rows, args.dim, 13, device=dev, opt=args.opt, lr=1e-3, seed=0)
+        from recommendation_amd.sharded import RcclComm, ShardedFactorizationMachine
+        # --comm rccl: the library's own RCCL entry points, enqueued on the compute stream itself (no hop to a
+        # collective stream and back per exchange); one communicator on one stream, so no side-stream id exchange
+        comm = RcclComm() if args.comm == 'rccl' else None
+        model = ShardedFactorizationMachine(rows, args.dim, 13, device=dev, opt=args.opt, lr=1e-3, seed=0, comm=comm)
     batches = gen_batches(8, B, rows, 13, args.dist, args.idx_bits, dev, seed=1000 + args.seed + rank)
 
     def barrier():
@@ -951,10 +956,11 @@ def main():
             i += nb
             continue
         kw = kws[i % nb]
-        if sharded and (args.prefetch or (world > 1 and not args.no_prefetch)):   # next batch's ids routed and exchanged beside this step's update
+        if sharded and args.comm != 'rccl' and (args.prefetch or (world > 1 and not args.no_prefetch)):   # next batch's ids routed and exchanged beside this step's update
             kw = {'next_ids': batches[(i + 1) % nb][0]}
         model.train_step(*batches[i % nb], **kw)
         i += 1
+    t_issue = time.perf_counter() - t0          # the host has enqueued every step; the device may still be running
     barrier()
     dt = time.perf_counter() - t0
     if sharded:
@@ -981,9 +987,14 @@ def main():
                                 else 'inside the step'),
                        'parallelism': 'single' if not sharded else 'rowwise-sharded tables x%d + replicated dense' % world},
         }
+        # time the host needed to enqueue a step: when it equals ms_per_step the step is bound by the host's
+        # launch / collective calls, not by the device
+        result['host_issue_ms_per_step'] = round(t_issue / args.steps * 1e3, 4)
         if sharded:
             result['config']['next_batch_id_exchange'] = ('beside the update (side stream)'
-                                                          if (args.prefetch or (world > 1 and not args.no_prefetch)) else 'in front of the step')
+                                                          if args.comm != 'rccl' and (args.prefetch or (world > 1 and not args.no_prefetch)) else 'in front of the step')
+            result['config']['collectives'] = ('torch.distributed (nccl backend = RCCL)' if args.comm != 'rccl' else
+                                               "the library's RCCL entry points on the compute stream")
     if not sharded:
         stages, U = stage_report(model, batches, args.stage_reps, args.idx_bits, tms)
         hbm = [s for s in stages if s['name'].startswith(('fm_fwd', 'fm_bwd_apply'))]

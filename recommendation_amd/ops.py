@@ -22,7 +22,17 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_RAW_DEVICE = getattr(torch._C, '_cuda_getDevice', None)
+if _RAW_DEVICE is None:
+    _RAW_STREAM = None
+
+
 def _stream():
+    # torch.cuda.current_stream() costs ~8 us a call (device-index resolution in Python), more than enqueueing
+    # the kernel it is asked for; the raw accessors are the ones torch's own compiled-graph runtime uses
+    if _RAW_STREAM is not None:
+        return ctypes.c_void_p(_RAW_STREAM(_RAW_DEVICE()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -148,8 +148,7 @@ class RcclComm(object):
 
     @staticmethod
     def _stream():
-        import ctypes
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return ops._stream()
 
     def all_to_all(self, out, inp):
         from . import _lib
