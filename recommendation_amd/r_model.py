@@ -55,7 +55,8 @@ class SparseFeature(object):
     @staticmethod
     def concat(parts):
         """tf.concat(..., axis=1) of one-hot matrices == ids shifted by the widths before them."""
-        if 1 < len(parts) <= ops.MI_MAX_ID_COLUMNS and len(set(p.ids.dtype for p in parts)) == 1:
+        if (1 < len(parts) <= ops.MI_MAX_ID_COLUMNS and len(set(p.ids.dtype for p in parts)) == 1 and
+                all(p.ids.is_cuda for p in parts)):    # one launch on the device; host tensors: plain index arithmetic
             return SparseFeature(ops.concat_id_columns([(p.ids, p.size) for p in parts]), sum(p.size for p in parts))
         ids, base = [], 0
         for p in parts:
