@@ -56,7 +56,7 @@ def parse_args():
                          'than the exchange they hide)')
     ap.add_argument('--no-prefetch', action='store_true', help='sharded path with several ranks: no next-batch id exchange beside the update')
     ap.add_argument('--comm', choices=['torch', 'rccl'], default='torch',
-                    help="sharded FM path: collectives through torch.distributed (default) or the library's own RCCL entry points")
+                    help="sharded paths: collectives through torch.distributed (default) or the library's own RCCL entry points")
     ap.add_argument('--din-full-rows', action='store_true',
                     help='DIN: materialise the full [q | k | q-k | q*k] rows instead of the factored first layer')
     ap.add_argument('--prefetch-sort', action='store_true',
@@ -559,7 +559,11 @@ def bench_sharded_embag(args):
     B = args.batch
     opt = args.opt if args.opt in ('sgd', 'adagrad_rowwise') else 'adagrad_rowwise'
     rows = [args.embag_rows * world // T] * T
-    m = ShardedEmbeddingBag(rows, D, L, dev, opt=opt, lr=0.01, seed=0)
+    comm = None
+    if args.comm == 'rccl':     # the library's own RCCL entry points, enqueued on the compute stream itself
+        from recommendation_amd.sharded import RcclComm
+        comm = RcclComm()
+    m = ShardedEmbeddingBag(rows, D, L, dev, opt=opt, lr=0.01, seed=0, comm=comm)
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + rank)
     card = torch.tensor(rows, dtype=torch.float64, device=dev).view(1, T, 1)
@@ -591,6 +595,7 @@ def bench_sharded_embag(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_issue = time.perf_counter() - t0          # the host has enqueued every step; the device may still be running
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -610,7 +615,10 @@ def bench_sharded_embag(args):
                           'optimizer': '%s (fused into the sparse backward)' % opt, 'launch': 'eager',
                           'placement': 'global row r on rank r %% %d as local row r / %d' % (world, world),
                           'capacity_rows_per_rank_pair': m.cap,
+                          'collectives': ('torch.distributed (nccl backend = RCCL)' if args.comm != 'rccl' else
+                                          "the library's RCCL entry points on the compute stream"),
                           'parallelism': 'rowwise-sharded tables x%d, pooled rows exchanged' % world}}
+        res['host_issue_ms_per_step'] = round(t_issue / args.steps * 1e3, 4)   # == ms_per_step when the host is the bound
         res['collectives'] = {'all_gather_ids_bytes_received': world * n_bags * L * ib,
                               'all_to_all_pooled_rows_bytes_per_rank': world * m.cap * D * 4,
                               'all_to_all_gradient_rows_bytes_per_rank': world * m.cap * D * 4,
