@@ -92,3 +92,20 @@ def test_no_cpu_fallback():
         ops.embag_fwd(torch.zeros((4, 4)), torch.tensor([0, 4]), 1, torch.zeros((2, 1), dtype=torch.int32))
     with pytest.raises(ops.MiError):
         ops.linear_fwd(torch.zeros((2, 3)), torch.zeros((3, 2)))
+
+
+def test_gradient_sink_allows_a_store_only_for_a_single_use_of_a_clean_slice():
+    """The rule behind storing a variable's gradient straight into the flat buffer (r_model._GradSink): exactly
+    one use since the last finished backward and nothing written since the slice was zeroed."""
+    from recommendation_amd.r_model import _GradSink
+    view = object()
+    s = _GradSink(view)
+    assert s.take() is None and s.dirty          # never used in a forward: nothing to store, and now marked written
+    s.dirty = False
+    s.uses = 1
+    assert s.take() is view and s.dirty          # the one use of a clean slice: store
+    assert s.take() is None                      # a second backward through the same op: accumulate
+    s.dirty, s.uses = False, 2
+    assert s.take() is None and s.take() is None  # two ops share the variable: both accumulate
+    s.uses = 1                                   # backward_done() + one forward, but no zero_grad in between
+    assert s.dirty and s.take() is None
