@@ -1,6 +1,8 @@
 // Sparse backward, step 2, for FM row records (single GPU and the owner side of row-wise sharded tables): the
 // entry points over the kernels of sparse_update.h, in a translation unit of their own so that the two
 // families of template instantiations compile side by side.
+#include <stdlib.h>
+
 #include "sparse_update.h"
 
 #ifdef SEG_TRACE
@@ -35,8 +37,12 @@ static int fm_bwd_apply_impl(const char* who, const mi_bwd_plan* plan, const mi_
   FmSrc src{g, S, g_ld, S_ld};
   OptArgs a{lr, beta1, beta2, eps, lr_dev};
   hipStream_t s = (hipStream_t) stream;
+  // records in the standard dim-16 layout: the updater that reads and writes whole 64-byte halves of lines
+  static const bool pack_off = getenv("MI355REC_FM_NO_PACK") != nullptr;
+  const bool pack = !pack_off && geo.vec == 4 && geo.lanes == 4 && fm_pack_layout_ok(*tab, opt);
   switch (opt) {
     case MI_OPT_SGD: {
+      if (pack) return run_segments(plan, pl, src, FmPackUpd<MI_OPT_SGD>{*tab, a}, geo, s, extra);
       FmUpd<MI_OPT_SGD> upd{*tab, a};
       return run_segments(plan, pl, src, upd, geo, s, extra);
     }
@@ -45,10 +51,12 @@ static int fm_bwd_apply_impl(const char* who, const mi_bwd_plan* plan, const mi_
         mi_set_error("%s: row-wise Adagrad needs dim/4 to be a power of two <= 64", who);
         return MI_ERR_UNSUPPORTED;
       }
+      if (pack) return run_segments(plan, pl, src, FmPackUpd<MI_OPT_ADAGRAD_ROWWISE>{*tab, a}, geo, s, extra);
       FmUpd<MI_OPT_ADAGRAD_ROWWISE> upd{*tab, a};
       return run_segments(plan, pl, src, upd, geo, s, extra);
     }
     case MI_OPT_ADAM_TF: {
+      if (pack) return run_segments(plan, pl, src, FmPackUpd<MI_OPT_ADAM_TF>{*tab, a}, geo, s, extra);
       FmUpd<MI_OPT_ADAM_TF> upd{*tab, a};
       return run_segments(plan, pl, src, upd, geo, s, extra);
     }

@@ -280,17 +280,24 @@ __device__ __forceinline__ void table_sort_body(int t, int part, int parts, cons
       }
     }
   } else {
-    // rank the samples by (key, lane); keys of more than 26 bits lose their low bits here, which only moves
-    // the cuts a little: any cut every workgroup of the table agrees on is a valid one.  Every wave holds all
-    // 64 samples; wave w counts how many of samples 4w..4w+3 precede each, and after one barrier every wave
-    // adds up the sixteen partial ranks for itself.
+    // rank the samples by (key, lane) - the FULL key: the cuts below are the composites (key, position) of the
+    // samples of certain ranks, position grows with the lane, so this ranking is exactly the order of the
+    // composites and the cuts ascend with the rank.  (A ranking on truncated keys lets two samples whose kept
+    // bits agree swap places against the composite order; the cuts are then not monotone, some parts are empty
+    // and their neighbours overlap.  Every part still writes each of its entries at that entry's global place -
+    // entries below its lower cut + entries selected before it - so the output stays right, but the overlapping
+    // parts do the same work twice, with a key span that wraps to 32 bits.)  Every wave holds all 64 samples;
+    // wave w counts how many of samples 4w..4w+3 precede each, and after one barrier every wave adds up the
+    // sixteen partial ranks for itself.
     const uint32_t skey = (sid >= 0 && sid < (int64_t) rows) ? (uint32_t) sid : rows;
-    const uint32_t s32 = ((skey >> (bits > 26 ? bits - 26 : 0)) << 6) | (uint32_t) lane;
     {
       uint32_t pr = 0;
 #pragma unroll
-      for (int j = 0; j < MI_WAVE / TS_WAVES; ++j)
-        pr += (uint32_t) __builtin_amdgcn_readlane((int) s32, w * (MI_WAVE / TS_WAVES) + j) < s32 ? 1u : 0u;
+      for (int j = 0; j < MI_WAVE / TS_WAVES; ++j) {
+        const int other = w * (MI_WAVE / TS_WAVES) + j;  // uniform over the wave
+        const uint32_t ok = (uint32_t) __builtin_amdgcn_readlane((int) skey, other);
+        pr += (ok < skey || (ok == skey && other < lane)) ? 1u : 0u;
+      }
       L.cnt[w][lane] = pr;
     }
     TS_MARK(11);
