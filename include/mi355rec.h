@@ -17,7 +17,11 @@
  *   - Bad ids are REPORTED, never clamped: kernels OR bits into the caller's device
  *     error word `err` (MI_IDERR_*), the entry skipped; the caller reads it back when it
  *     wants the check (the reference raises InvalidArgumentError at session.run).
- *   - Re-entrant across distinct streams and workspaces; no global state.
+ *   - Re-entrant across distinct streams and workspaces.  The library's only state of its own: the
+ *     per-thread error string; the RCCL communicators behind mi_comm_* handles (one table per
+ *     process); and the built-in scratch array of mi_embag_bwd_prepare_noalloc (one copy per
+ *     device, shared by every call on that device - see its comment).  Everything else lives in
+ *     the caller's buffers.
  */
 #ifndef MI355REC_H
 #define MI355REC_H
@@ -145,7 +149,11 @@ int mi_embag_bwd_prepare(const int64_t* table_offsets, int T, int64_t total_rows
  * more returns MI_ERR_WORKSPACE.  The call itself allocates nothing and frees nothing.  All calls on
  * one GPU share that array: two calls that overlap in time on the same GPU (different streams or
  * threads) race; calls on one stream, or on different GPUs, do not.  The array keeps the previous
- * call's contents; every part of it is rewritten before it is read, so nothing needs clearing. */
+ * call's contents; every part of it is rewritten before it is read, so nothing needs clearing.
+ * The FIRST call on each device looks the array's device address up (hipGetSymbolAddress), which a
+ * capturing stream cannot record: make that call outside stream capture - one with n_entries = 0
+ * (its buffers may be NULL) does the lookup and launches nothing; under capture an unresolved address returns
+ * MI_ERR_UNSUPPORTED.  Later calls on that device may be captured and replayed. */
 #define MI_NOALLOC_MAX_ENTRIES (1 << 21)
 int mi_embag_bwd_prepare_noalloc(const int64_t* table_offsets, int T, int64_t total_rows,
                                  const void* indices, int idx_bits, const int64_t* offsets, int bag_len,

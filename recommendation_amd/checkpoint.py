@@ -60,14 +60,21 @@ def save(checkpoint_dir, model, optimizer=None, step=None, fmt='npz'):
     os.makedirs(checkpoint_dir, exist_ok=True)
     values = variables_of(model, optimizer)
     step = int(values['global_step']) if step is None else int(step)
+    values['global_step'] = np.int64(step)           # the file's name and its global_step agree
     name = 'model.ckpt-%d' % step
+    if fmt not in ('npz', 'bundle'):
+        raise ValueError("fmt must be 'npz' or 'bundle'")
+    # one container per step: ``latest`` prefers the bundle of a name, so a bundle left from an earlier save of
+    # this step would shadow the .npz written now (and the other way round a stale .npz would linger)
+    stale = [name + '.npz'] if fmt == 'bundle' else [name + '.index', name + '.data-00000-of-00001']
+    for f in stale:
+        if os.path.exists(os.path.join(checkpoint_dir, f)):
+            os.remove(os.path.join(checkpoint_dir, f))
     if fmt == 'bundle':
         path = tf_bundle.write_bundle(os.path.join(checkpoint_dir, name), {k: np.asarray(v) for k, v in values.items()})
-    elif fmt == 'npz':
+    else:
         path = os.path.join(checkpoint_dir, name + '.npz')
         np.savez(path, **values)
-    else:
-        raise ValueError("fmt must be 'npz' or 'bundle'")
     with open(os.path.join(checkpoint_dir, 'checkpoint'), 'w') as f:
         f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (name, name))
     return path
@@ -89,12 +96,13 @@ def latest(checkpoint_dir):
     return None
 
 
-def read_values(path):
-    """name -> array of a checkpoint: a bundle prefix (or its .index file) or an .npz."""
+def read_values(path, skipped=None):
+    """name -> array of a checkpoint: a bundle prefix (or its .index file) or an .npz.  Bundle entries this reader
+    cannot represent are left out (tf_bundle.read_bundle; their names go to ``skipped``)."""
     if path.endswith('.index'):
         path = path[:-len('.index')]
     if os.path.exists(path + '.index'):
-        return tf_bundle.read_bundle(path)
+        return tf_bundle.read_bundle(path, skipped=skipped)
     with np.load(path, allow_pickle=False) as z:
         return {k: z[k] for k in z.files}
 
@@ -105,7 +113,12 @@ def load(path_or_dir, model, optimizer=None):
     path = latest(path_or_dir) if os.path.isdir(path_or_dir) else path_or_dir
     if path is None:
         raise FileNotFoundError("no checkpoint under %s" % path_or_dir)
-    values = read_values(path)
+    skipped = []
+    values = read_values(path, skipped)
+    needed = set(model._slots) if getattr(model, '_slots', None) else set()
+    lost = [(n, why) for n, why in skipped if n in needed]
+    if lost:
+        raise tf_bundle.BundleError("checkpoint %s: %s" % (path, "; ".join("%s: %s" % nw for nw in lost)))
     slots = ('/Adam', '/Adam_1')
     model.load_variables({k: v for k, v in values.items()
                           if not k.endswith(slots) and k not in ('beta1_power', 'beta2_power', 'global_step')})

@@ -552,13 +552,20 @@ void* g_noalloc_ptr[NOALLOC_MAX_DEVICES];
 std::mutex g_noalloc_mutex;
 
 // Device address of this device's copy of noalloc_scratch (looked up on the first call per device).
-int noalloc_scratch_ptr(void** out) {
+int noalloc_scratch_ptr(void** out, hipStream_t stream) {
   int dev = -1;
   MI_HIP(hipGetDevice(&dev));
   MI_REQUIRE(dev >= 0 && dev < NOALLOC_MAX_DEVICES, "mi_embag_bwd_prepare_noalloc: device %d outside 0..%d", dev,
              NOALLOC_MAX_DEVICES - 1);
   std::lock_guard<std::mutex> lock(g_noalloc_mutex);
   if (!g_noalloc_ptr[dev]) {
+    // the lookup resolves a symbol of the code object: not an operation a capturing stream can record
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+      mi_set_error("mi_embag_bwd_prepare_noalloc: the first call on a device must be made outside stream capture "
+                   "(a call with n_entries = 0 resolves the scratch address and launches nothing)");
+      return MI_ERR_UNSUPPORTED;
+    }
     void* p = nullptr;
     MI_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(noalloc_scratch)));
     MI_REQUIRE(p && ((uintptr_t) p & 255) == 0, "mi_embag_bwd_prepare_noalloc: scratch symbol not resolved");
@@ -581,8 +588,9 @@ extern "C" int mi_embag_bwd_prepare_noalloc(const int64_t* table_offsets, int T,
     return MI_ERR_WORKSPACE;
   }
   void* ws = nullptr;
-  const int rc = noalloc_scratch_ptr(&ws);
+  const int rc = noalloc_scratch_ptr(&ws, (hipStream_t) stream);
   if (rc != MI_OK) return rc;
+  if (n_entries == 0 && (!indices || !sorted_rows || !perm)) return MI_OK;  // a warm-up call: the address is resolved
   // every buffer carved from the scratch is fully written before it is read (alternate key / value
   // buffers by key generation or a pass, histograms and block counts by their own kernels), so
   // nothing of the previous call's contents needs clearing

@@ -421,8 +421,12 @@ def list_variables(prefix, verify=True):
     return out
 
 
-def read_bundle(prefix, verify=True):
-    """name -> numpy array for every tensor of the bundle ``prefix`` (.index + .data-* files)."""
+def read_bundle(prefix, verify=True, skipped=None):
+    """name -> numpy array for every tensor of the bundle ``prefix`` (.index + .data-* files) that this reader can
+    represent.  Entries it cannot - a dtype without a numpy counterpart here (DT_STRING such as TensorFlow 2's
+    ``_CHECKPOINTABLE_OBJECT_GRAPH``, bfloat16 ...) or a partitioned (sliced) variable - are left out, their names
+    and the reason appended to ``skipped`` when a list is given: a checkpoint that carries such an entry beside
+    the model's variables still restores; whoever needs the entry finds it missing."""
     with open(prefix + '.index', 'rb') as f:
         pairs = read_table(f.read(), verify)
     if not pairs or pairs[0][0] != b'':
@@ -436,10 +440,11 @@ def read_bundle(prefix, verify=True):
     for k, v in pairs[1:]:
         e = decode_entry(v)
         name = k.decode()
-        if e['slices']:
-            raise BundleError("%s: partitioned (sliced) variables are not supported" % name)
-        if e['dtype'] not in _DTYPES:
-            raise BundleError("%s: unsupported dtype code %d" % (name, e['dtype']))
+        if e['slices'] or e['dtype'] not in _DTYPES:
+            if skipped is not None:
+                skipped.append((name, "partitioned (sliced) variable" if e['slices']
+                                else "unsupported dtype code %d" % e['dtype']))
+            continue
         dt = np.dtype(_DTYPES[e['dtype']])
         count = int(np.prod(e['shape'], dtype=np.int64)) if e['shape'] else 1
         if count * dt.itemsize != e['size']:

@@ -90,9 +90,10 @@ class GraphedTrainStep(object):
       beta2_power} inside the graph; the host copy of the schedule is advanced beside it for checkpoints),
     * the id error word is read every ``check_every`` replays (and by ``check()``) instead of in every
       ``features`` call: a bad id is never dereferenced meanwhile, it is just reported a few steps later.
-    A batch of another size (the ragged last batch of an epoch) runs the eager step.  The tensors returned by
+    A batch of another shape (the ragged last batch of an epoch, recommend lists of another width) runs the eager step.  The tensors returned by
     a replay are the graph's own output buffers: the next call overwrites them.  Single process only (the
-    data-parallel all-reduce is not captured)."""
+    data-parallel all-reduce is not captured: a captured collective could not be exercised by this build, which has
+    no second GPU to run two RCCL ranks on, so the data-parallel step stays eager)."""
 
     def __init__(self, model, optimizer, columns, check_every=64):
         if torch.distributed.is_available() and torch.distributed.is_initialized() and \
@@ -161,12 +162,15 @@ class GraphedTrainStep(object):
     def __call__(self, columns):
         """Same result tuple as train_step: (acc, labels, top_indices, loss, global_step)."""
         m = self.model
-        if int(columns[0].shape[0]) != self.batch:
+        ins = [m._ids(c) for c in columns]
+        # any column of another shape than the captured one - a ragged last batch, or a batch whose recommend
+        # lists have another width - takes the eager step; the device's schedule is brought back in line after it
+        if len(ins) != len(self.static_in) or any(tuple(a.shape) != tuple(b.shape) for a, b in zip(ins, self.static_in)):
             res = train_step(m, self.opt, columns)
             self._sched_to_device()
             return res
-        for dst, src in zip(self.static_in, columns):
-            dst.copy_(src.reshape(dst.shape), non_blocking=True)
+        for dst, src in zip(self.static_in, ins):
+            dst.copy_(src, non_blocking=True)
         m._in_graph = True
         try:
             self.graph.replay()
@@ -181,18 +185,37 @@ class GraphedTrainStep(object):
 
 
 def train(files, batch_size=300, last_step=5000, learning_rate=1e-4, device='cuda:0', seed=None, parallelism=None,
-          index=None, log_every=100, model=None, process_group=None, graph=False):
+          index=None, log_every=100, model=None, process_group=None, graph=False, checkpoint_dir=None,
+          save_checkpoint_steps=None, checkpoint_format='npz', resume_input=False, is_chief=None):
     """The loop of local_train_utils.train (:30-66) / ModelTrainer.train's worker branch
     (model_trainer.py:138-179): same model constants, batch size, optimizer and stop step.
-    ``graph=True`` replays the step as a captured HIP graph (single process; see GraphedTrainStep)."""
+    ``graph=True`` replays the step as a captured HIP graph (single process; see GraphedTrainStep).
+
+    ``checkpoint_dir`` is MonitoredTrainingSession's (local_train_utils.py:54-58, model_trainer.py:160-169): when
+    the directory holds a checkpoint, variables, Adam slots, schedule and global step are restored on entry and
+    the loop runs on until the GLOBAL step reaches ``last_step`` (StopAtStepHook(last_step=...)); a checkpoint is
+    written every ``save_checkpoint_steps`` steps (the reference saves by wall-clock time - every 600 s by default,
+    30 / 60 s in its batch / stream jobs, model_trainer.py:230-233,196-199 - which has no reproducible counterpart)
+    and when the loop ends, by the chief only (rank 0 unless ``is_chief`` says otherwise; model_trainer.py:164).
+    As in the reference the input starts over after a restore; ``resume_input=True`` instead skips the batches the
+    restored steps consumed, which makes an interrupted run continue bit for bit like an uninterrupted one."""
+    from . import checkpoint
     m = model or RecommendationModel(colour_count=128, recommend_num=6, user_count=100, country_count=20,
                                      device=device, seed=seed)
     dataset = Sample.read_label_data(files, batch_size=batch_size, parallelism=parallelism, index=index)
     iterator = dataset.make_one_shot_iterator()
     optimizer = AdamOptimizer(learning_rate=learning_rate)
+    if is_chief is None:
+        is_chief = not index
     step = 0
+    if checkpoint_dir is not None and checkpoint.latest(checkpoint_dir) is not None:
+        step = checkpoint.load(checkpoint_dir, m, optimizer)
+        if resume_input:
+            for _ in range(step):
+                iterator.get_next()
     history = []
     graphed = None
+    saved_at = step
     while step < last_step:
         columns = iterator.get_next()
         step += 1
@@ -205,6 +228,13 @@ def train(files, batch_size=300, last_step=5000, learning_rate=1e-4, device='cud
         if log_every and step % log_every == 0:
             history.append((step, float(loss_res), float(acc_res)))
             print("Train step %d, loss: %f accuracy: %f" % (step, float(loss_res), float(acc_res)))
+        if checkpoint_dir is not None and is_chief and save_checkpoint_steps and step % save_checkpoint_steps == 0:
+            if graphed is not None:
+                graphed.check()                     # never save parameters a bad id may have spoilt unnoticed
+            checkpoint.save(checkpoint_dir, m, optimizer, step=step, fmt=checkpoint_format)
+            saved_at = step
     if graphed is not None:
         graphed.check()
+    if checkpoint_dir is not None and is_chief and saved_at != step:
+        checkpoint.save(checkpoint_dir, m, optimizer, step=step, fmt=checkpoint_format)
     return m, optimizer, history

@@ -9,10 +9,13 @@ import pytest
 import torch
 
 from oracle import colour_model as cm
+from tests.errlog import held
 from tests.test_golden import load_colour
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-5
+ADAM_TOL = 1e-5      # Adam-updated parameters against the fp64 oracle after two steps (achieved: <= 1e-7)
+ADAM_TOL_40 = 1e-5   # ... and after a 40-step trajectory (achieved: <= 1.3e-6)
 
 
 def rel_err(a, b):
@@ -161,7 +164,7 @@ def test_first_layer_gradient_is_the_dense_tensorflow_gradient(dev):
     moved_without_grad = [r for r in set(batch['user'].tolist()) - set(batch2['user'].tolist())]
     assert moved_without_grad
     for n in p64:
-        assert rel_err(m.variables[n].cpu().numpy(), p64[n]) <= 1e-4, n
+        held("colour 2 Adam steps %s" % n, rel_err(m.variables[n].cpu().numpy(), p64[n]), ADAM_TOL)
     assert np.abs(got[moved_without_grad] - params['dense/kernel'][moved_without_grad]).min() > 1e-4
 
 
@@ -234,11 +237,11 @@ def test_train_loop_from_files_follows_the_oracle_trajectory(dev, tmp_path):
             want.append((step + 1, float(loss), float(acc)))
     assert opt.t == 40 and [h[0] for h in hist] == [10, 20, 30, 40]
     for (s, l, a), (_, wl, wa) in zip(hist, want):
-        assert abs(l - wl) <= 1e-4 * wl, (s, l, wl)
+        held("colour trajectory loss at step %d" % s, abs(l - wl) / wl, 1e-4)
         assert abs(a - wa) <= 1.0 / 300 + 1e-6, (s, a, wa)
     assert hist[-1][1] < hist[0][1]
     for n in p64:
-        assert rel_err(m.variables[n].cpu().numpy(), p64[n]) <= 1e-4, n
+        held("colour 40-step trajectory %s" % n, rel_err(m.variables[n].cpu().numpy(), p64[n]), ADAM_TOL_40)
 
 
 def test_graphed_train_step_equals_eager_bit_for_bit(dev):

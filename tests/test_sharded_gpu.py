@@ -5,6 +5,9 @@ import pytest
 import torch
 
 from oracle import fm as ofm
+from tests.errlog import held
+
+ADAM_TOL = 3e-5   # sharded against single-GPU Adam, V after three steps (achieved: 1.5e-5; twice that)
 
 pytestmark = pytest.mark.gpu
 
@@ -43,12 +46,12 @@ def test_sharded_equals_single_gpu(dev, N, opt):
     for r, m in enumerate(shards):
         v, w = m.be.rows()
         V[r::N], w1[r::N] = v.cpu().numpy(), w.cpu().numpy()
-    tol = 1e-4 if opt == "adam_tf" else 1e-5      # Adam: see test_fm_train_step
-    assert rel_err(V, single.V.cpu().numpy()) <= tol
-    assert rel_err(w1, single.w1.cpu().numpy()) <= tol
+    tol = ADAM_TOL if opt == "adam_tf" else 1e-5      # Adam: see test_fm_train_step
+    held("sharded FM N=%d %s V" % (N, opt), rel_err(V, single.V.cpu().numpy()), tol)
+    held("sharded FM N=%d %s w1" % (N, opt), rel_err(w1, single.w1.cpu().numpy()), 1e-5)
     for m in shards:                              # dense side: replicas agree bit for bit
         assert torch.equal(m.dp, shards[0].dp)
-    assert rel_err(shards[0].dp.cpu().numpy(), single.dp.cpu().numpy()) <= tol
+    held("sharded FM N=%d %s dense" % (N, opt), rel_err(shards[0].dp.cpu().numpy(), single.dp.cpu().numpy()), 1e-5)
 
 
 def test_sharded_equals_single_gpu_ragged_batch(dev):
@@ -77,11 +80,11 @@ def test_sharded_equals_single_gpu_ragged_batch(dev):
     for r, m in enumerate(shards):
         v, w = m.be.rows()
         V[r::N], w1[r::N] = v.cpu().numpy(), w.cpu().numpy()
-    assert rel_err(V, single.V.cpu().numpy()) <= 1e-5
-    assert rel_err(w1, single.w1.cpu().numpy()) <= 1e-5
+    held("sharded FM N=3 sgd ragged V", rel_err(V, single.V.cpu().numpy()), 1e-5)
+    held("sharded FM N=3 sgd ragged w1", rel_err(w1, single.w1.cpu().numpy()), 1e-5)
     for m in shards:
         assert torch.equal(m.dp, shards[0].dp)
-    assert rel_err(shards[0].dp.cpu().numpy(), single.dp.cpu().numpy()) <= 1e-4
+    held("sharded FM N=3 sgd ragged dense", rel_err(shards[0].dp.cpu().numpy(), single.dp.cpu().numpy()), 1e-4)
 
 
 def test_sharded_equals_single_gpu_full_batch_hot_rows(dev):
@@ -110,7 +113,7 @@ def test_sharded_equals_single_gpu_full_batch_hot_rows(dev):
     for r, m in enumerate(shards):
         V[r::N] = m.be.rows()[0].cpu().numpy()
     # the hot rows sum 16384 terms in different (fixed) orders on the two paths
-    assert rel_err(V, single.V.cpu().numpy()) <= 1e-4
+    held("sharded FM N=2 B=8192 hot rows V", rel_err(V, single.V.cpu().numpy()), 1e-4)
 
 
 def test_routing_artefacts_bit_exact(dev):

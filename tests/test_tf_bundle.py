@@ -162,3 +162,59 @@ def test_first_layer_split_and_merge():
     assert np.array_equal(ck.merge_first_layer(R, K), k)
     with pytest.raises(ValueError):
         ck.split_first_layer(k, 100)
+
+
+def test_entries_the_reader_cannot_represent_are_skipped_not_fatal(tmp_path):
+    """A bundle that carries, beside the model's variables, a DT_STRING entry (TensorFlow 2 writes
+    _CHECKPOINTABLE_OBJECT_GRAPH that way) or a bfloat16 tensor still reads: those entries are left out and named."""
+    prefix = str(tmp_path / 'model.ckpt-7')
+    w = np.arange(12, dtype=np.float32).reshape(3, 4)
+    blob = b'\x0a\x03abc'
+    bf = np.array([1, 2, 3], dtype=np.uint16).tobytes()
+    raw = w.tobytes() + blob + bf
+    with open(tb._shard_name(prefix, 0, 1), 'wb') as f:
+        f.write(raw)
+    pairs = [(b'', tb.encode_header(1)),
+             (b'_CHECKPOINTABLE_OBJECT_GRAPH', tb.encode_entry(7, (), 0, len(w.tobytes()), len(blob), tb.mask_crc(tb.crc32c(blob)))),
+             (b'dense/kernel', tb.encode_entry(1, w.shape, 0, 0, len(w.tobytes()), tb.mask_crc(tb.crc32c(w.tobytes())))),
+             (b'half', tb.encode_entry(14, (3,), 0, len(w.tobytes()) + len(blob), len(bf), tb.mask_crc(tb.crc32c(bf))))]
+    with open(prefix + '.index', 'wb') as f:
+        f.write(tb.write_table(pairs))
+    skipped = []
+    got = tb.read_bundle(prefix, skipped=skipped)
+    assert list(got) == ['dense/kernel'] and np.array_equal(got['dense/kernel'], w)
+    assert [n for n, _ in skipped] == ['_CHECKPOINTABLE_OBJECT_GRAPH', 'half']
+    assert tb.read_bundle(prefix).keys() == got.keys()          # no list given: silently left out
+
+
+class _FakeModel(object):
+    """What checkpoint.save / load touch of a model."""
+
+    def __init__(self, values):
+        import torch
+        self.variables = {k: torch.from_numpy(np.array(v, dtype=np.float32)) for k, v in values.items()}
+        self._slots = {}
+
+    def load_variables(self, values):
+        import torch
+        for k, v in values.items():
+            self.variables[k] = torch.from_numpy(np.array(v, dtype=np.float32))
+
+
+def test_a_step_saved_twice_keeps_one_container(tmp_path):
+    """latest() prefers the bundle of a name; a later .npz save of the same step must not be shadowed by it."""
+    from recommendation_amd import checkpoint
+    d = str(tmp_path)
+    checkpoint.save(d, _FakeModel({'dense/kernel': [[1.0, 2.0]]}), step=5, fmt='bundle')
+    assert os.path.exists(os.path.join(d, 'model.ckpt-5.index'))
+    checkpoint.save(d, _FakeModel({'dense/kernel': [[3.0, 4.0]]}), step=5, fmt='npz')
+    assert not os.path.exists(os.path.join(d, 'model.ckpt-5.index'))
+    assert not os.path.exists(os.path.join(d, 'model.ckpt-5.data-00000-of-00001'))
+    m = _FakeModel({})
+    assert checkpoint.load(d, m) == 5
+    assert m.variables['dense/kernel'].tolist() == [[3.0, 4.0]]
+    checkpoint.save(d, _FakeModel({'dense/kernel': [[5.0, 6.0]]}), step=5, fmt='bundle')
+    assert not os.path.exists(os.path.join(d, 'model.ckpt-5.npz'))
+    m = _FakeModel({})
+    checkpoint.load(d, m)
+    assert m.variables['dense/kernel'].tolist() == [[5.0, 6.0]]

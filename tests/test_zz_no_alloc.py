@@ -81,3 +81,34 @@ def test_noalloc_prepare_rejects_sizes_beyond_its_scratch(dev):
     sr, pm = torch.empty((n - 1,), dtype=torch.int32, device=dev), torch.empty((n - 1,), dtype=torch.int32, device=dev)
     ops.bwd_prepare_noalloc(ops.table_offsets([10], dev), 1, 10, ids, sr, pm)
     assert torch.equal(sr, torch.sort(ids.view(-1), stable=True)[0])
+
+
+def test_noalloc_prepare_replays_from_a_captured_graph(dev):
+    """After one call outside capture (here with no entries: it resolves the scratch address and launches nothing) the
+    call can be captured in a HIP graph; a replay on new ids gives mi_embag_bwd_prepare's bits."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(78)
+    rows = [3, 1000, 100000, 24]
+    T, ids, toffs = _problem(rng, 5000, rows, 2)
+    total = int(toffs[-1])
+    td, idd = torch.from_numpy(toffs).to(dev), torch.from_numpy(ids).to(dev)
+    n = ids.size
+    i32 = dict(dtype=torch.int32, device=dev)
+    sr, pm = torch.empty((n,), **i32), torch.empty((n,), **i32)
+    ur, so, ct = torch.empty((n,), **i32), torch.empty((n + 1,), **i32), torch.empty((2,), **i32)
+    ops.bwd_prepare_noalloc(td, T, total, idd[:0], sr, pm, ur, so, ct, bag_len=2)     # warm-up: no entries
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ops.bwd_prepare_noalloc(td, T, total, idd, sr, pm, ur, so, ct, bag_len=2)
+    for seed in (1, 2):
+        _, ids2, _ = _problem(np.random.default_rng(seed), 5000, rows, 2)
+        idd.copy_(torch.from_numpy(ids2))
+        g.replay()
+        torch.cuda.synchronize()
+        ref = ops.SortedPlan(td, T, total, idd, bag_len=2, runs=True)
+        n_unique, n_valid = ref.counts.tolist()
+        assert ct.tolist() == [n_unique, n_valid]
+        assert torch.equal(sr, ref.sorted_rows) and torch.equal(pm[:n_valid], ref.perm[:n_valid])
+        assert torch.equal(ur[:n_unique], ref.unique_rows[:n_unique])
+        assert torch.equal(so[:n_unique + 1], ref.seg_offsets[:n_unique + 1])
