@@ -74,6 +74,8 @@ def parse_args():
                     help='embag workload: total rows over the 26 tables (default: one GPU\'s eighth of 1 G rows); '
                          'sharded_embag: rows PER RANK')
     ap.add_argument('--din-items', type=int, default=8000000, help='din workload: rows of the item table')
+    ap.add_argument('--no-host-fed', action='store_true',
+                    help='fm workload: skip the extra line that feeds every batch from pinned host memory')
     ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer', 'embag', 'sharded_embag', 'colour'],
                     help='fm (default, the headline configuration); dcn / din: the bf16 matrix-core configurations, 1 GPU')
     args = ap.parse_args()
@@ -252,6 +254,97 @@ def stage_report(fm, batches, reps, idx_bits, tms=None):
     for dst, src in zip((fm.table.rec, fm.dp, fm.dm, fm.dv, fm.sched), saved):
         dst.copy_(src)
     return stages, U
+
+
+def host_fed_line(model, batches, steps, dev, resident_ms):
+    """The same step with every batch copied in from pinned host memory, as the reference's loop reads its batch
+    every step (recommendation/local_train_utils.py:34-41,60-63): int32 ids field-major + dense + labels go over
+    PCIe as one block on a side stream into one of two device buffer sets while the step of the previous batch runs on the other
+    (events order copy -> step -> next copy into that set).  Returns samples/s of that pipeline, of the copies
+    alone, and which of the two bounds it."""
+    from recommendation_amd import ops
+    B, T = batches[0][0].shape
+    nb = len(batches)
+    nd = batches[0][1].shape[1]
+    # ONE pinned block per batch - ids | dense | labels at 256-byte aligned offsets - so a batch is one copy: three
+    # separate copies of 852 KB, 426 KB and 32 KB cost ~70 us of call overhead each and moved 6 GB/s
+    sizes = [T * B * 4, B * nd * 4, B * 4]
+    offs = [0, -(-sizes[0] // 256) * 256]
+    offs.append(offs[1] + -(-sizes[1] // 256) * 256)
+    total = offs[2] + -(-sizes[2] // 256) * 256
+    nbytes = sum(sizes)
+
+    def views(block):
+        return (block[offs[0]:offs[0] + sizes[0]].view(torch.int32).view(T, B),
+                block[offs[1]:offs[1] + sizes[1]].view(torch.float32).view(B, nd),
+                block[offs[2]:offs[2] + sizes[2]].view(torch.float32).view(B))
+
+    host = []
+    for b in batches:
+        blk = torch.empty((total,), dtype=torch.uint8).pin_memory()
+        v = views(blk)
+        v[0].copy_(b[0].t().to(torch.int32))
+        v[1].copy_(b[1])
+        v[2].copy_(b[2])
+        host.append(blk)
+    shape_only = torch.empty((B, T), dtype=torch.int32, device=dev)      # the step reads the field-major copy
+    dblk = [torch.empty((total,), dtype=torch.uint8, device=dev) for _ in range(2)]
+    bufs = [views(d) for d in dblk]
+    side = torch.cuda.Stream(dev)
+    copied = [torch.cuda.Event() for _ in range(2)]
+    used = [torch.cuda.Event() for _ in range(2)]
+    model.train_step(shape_only, bufs[0][1], bufs[0][2], ids_tm=bufs[0][0])     # buffers of this shape exist before capture
+    torch.cuda.synchronize()
+    # One replay = the run's nb batches: copy of batch i+1 (side stream) beside the step on batch i (capturing stream),
+    # ordered by events inside the graph.  Issued eagerly the same pipeline is bound by the host (~60 us of stream
+    # and event calls per step).
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cap = torch.cuda.current_stream()
+        side.wait_stream(cap)
+        with torch.cuda.stream(side):
+            ops.stage_from_host(dblk[0], host[0])
+            copied[0].record(side)
+        for i in range(nb):
+            k = i % 2
+            if i + 1 < nb:
+                with torch.cuda.stream(side):
+                    if i >= 1:
+                        side.wait_event(used[k ^ 1])       # step i-1 was the last reader of that buffer set
+                    ops.stage_from_host(dblk[k ^ 1], host[i + 1])
+                    copied[k ^ 1].record(side)
+            cap.wait_event(copied[k])
+            model.train_step(shape_only, bufs[k][1], bufs[k][2], ids_tm=bufs[k][0])
+            used[k].record(cap)
+        cap.wait_stream(side)
+    reps = max(2, steps // nb)
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        graph.replay()
+    torch.cuda.synchronize()
+    t_pipe = (time.perf_counter() - t0) / (reps * nb)
+    cur = torch.cuda.current_stream()
+    for j in range(4):
+        ops.stage_from_host(dblk[j % 2], host[j % nb])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for j in range(reps * nb):
+        ops.stage_from_host(dblk[j % 2], host[j % nb])
+    torch.cuda.synchronize()
+    t_copy = (time.perf_counter() - t0) / (reps * nb)
+    return {'value': round(B / t_pipe, 1), 'unit': 'samples/s', 'ms_per_step': round(t_pipe * 1e3, 4),
+            'bytes_per_batch': nbytes, 'ids': 'int32, field-major [T][B]',
+            'copy_only_ms_per_batch': round(t_copy * 1e3, 4), 'copy_only_gbs': round(nbytes / t_copy / 1e9, 1),
+            # a perfect overlap would cost max(copy, step) per step; what is lost to the two cross-stream edges a step
+            # adds inside the graph and to the copy kernel sharing the chip shows as overlap < 1
+            'bound': 'host-to-device copy' if t_copy * 1e3 > resident_ms else 'step',
+            'overlap': round(max(t_copy * 1e3, resident_ms) / (t_pipe * 1e3), 3),
+            'how': 'pinned host memory, one block per batch copied by a kernel (mi_stage_from_host) on a side stream '
+                   'into one of two device buffer sets beside the step on the other; %d steps and their copies '
+                   'replayed as one HIP graph' % nb}
 
 
 def host_cores():
@@ -1019,7 +1112,7 @@ def main():
         # HBM bytes per launch of that kernel from the PMC counters: they cannot be collected from inside
         # this process, so the committed measurement of this same workload is quoted (null for any other)
         traffic, traffic_source = None, None
-        for fname in ('r02_fm_b8192_pmc.json', 'r01_fm_b8192_pmc.json'):
+        for fname in ('r03_fm_b8192_pmc.json', 'r02_fm_b8192_pmc.json', 'r01_fm_b8192_pmc.json'):
             pmc_path = os.path.join(ROOT, 'profiles', fname)
             if upd and os.path.exists(pmc_path):
                 pmc = json.load(open(pmc_path))
@@ -1034,6 +1127,8 @@ def main():
                               'alg_bytes_per_launch': dom['alg_bytes'], 'ms_per_launch': dom['ms']}
         emb = [s for s in hbm]
         result['embedding_hbm_gbs'] = round(sum(s['alg_bytes'] for s in emb) / sum(s['ms'] for s in emb) / 1e6, 1)
+        if not args.no_host_fed and use_graph and B <= model._fused_max:
+            result['host_fed'] = host_fed_line(model, batches, min(args.steps, 200), dev, ms)
         if not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args, rows, model, batches)
     if sharded and rank == 0:

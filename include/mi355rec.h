@@ -113,6 +113,16 @@ int mi_validate_id_columns(const mi_id_column* cols, int n_cols, int idx_bits, i
  * [B][sum of bag_len] of the same integer type. */
 int mi_concat_id_columns(const mi_id_column* cols, int n_cols, int idx_bits, int64_t B, void* out, void* stream);
 
+/* Batch staging: dst[0..bytes) (device) = src[0..bytes), where src is host memory that the device can read
+ * (pinned / registered: hipHostMalloc, hipHostRegister, torch pin_memory), copied by a KERNEL on `stream`.
+ * The reference's loop reads a batch from its dataset iterator every step (local_train_utils.py:34-41,60-63 -
+ * tf.data feeds the session); here a batch crosses PCIe once per step, and this is the copy for callers that
+ * overlap it with the previous step on another stream: a copy kernel orders with compute kernels through device-side
+ * stream dependencies (microseconds), whereas a copy-engine transfer (hipMemcpyAsync) and a kernel that wait on
+ * each other go through the host runtime's event thread (~100 us per hand-over, measured).  Both pointers and
+ * bytes must be multiples of 16. */
+int mi_stage_from_host(void* dst, const void* src_host, size_t bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Sparse backward, step 1: deterministic sort by (table,row).
  * Entry p (position in `indices`) gets key = table_offsets[t] + id (a global row, uint32;

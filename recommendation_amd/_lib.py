@@ -65,6 +65,7 @@ _SIGNATURES = {
     'mi_validate_ids': (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P, P]),
     'mi_validate_id_columns': (c_int, [P, c_int, c_int, P, P]),
     'mi_concat_id_columns': (c_int, [P, c_int, c_int, c_int64, P, P]),
+    'mi_stage_from_host': (c_int, [P, P, c_size_t, P]),
     'mi_embag_bag_info': (c_int, [P, c_int, P, c_int, P, c_int, c_int64, P, P, P]),
     'mi_embag_bwd_workspace_bytes': (c_size_t, [c_int64]),
     'mi_embag_bwd_prepare': (c_int, [P, c_int, c_int64, P, c_int, P, c_int, c_int64, c_int64, P, P, P, P, P,

@@ -673,3 +673,41 @@ extern "C" int mi_concat_id_columns(const mi_id_column* cols, int n_cols, int id
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
+
+// ---- batch staging -------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void stage_copy_kernel(float4* __restrict__ dst, const float4* __restrict__ src,
+                                                         size_t n) {
+  // eight 16-byte reads per thread in flight: the reads cross PCIe, a round trip of microseconds
+  const size_t base = ((size_t) blockIdx.x * 256 + threadIdx.x);
+  const size_t stride = (size_t) gridDim.x * 256;
+  for (size_t i = base; i < n; i += 8 * stride) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t j = i + u * stride;
+      v[u] = src[j < n ? j : i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t j = i + u * stride;
+      if (j < n) dst[j] = v[u];
+    }
+  }
+}
+}  // namespace
+
+extern "C" int mi_stage_from_host(void* dst, const void* src_host, size_t bytes, void* stream) {
+  const char* who = "mi_stage_from_host";
+  MI_REQUIRE(dst && src_host, "%s: null pointer", who);
+  MI_REQUIRE(bytes % 16 == 0 && ((uintptr_t) dst & 15) == 0 && ((uintptr_t) src_host & 15) == 0,
+             "%s: pointers and size must be multiples of 16", who);
+  if (bytes == 0) return MI_OK;
+  const size_t n = bytes / 16;
+  const size_t want = (n + 256 * 8 - 1) / (256 * 8);
+  const unsigned grid = (unsigned) (want < 1024 ? want : 1024);
+  hipLaunchKernelGGL(stage_copy_kernel, dim3(grid), dim3(256), 0, (hipStream_t) stream, (float4*) dst,
+                     (const float4*) src_host, n);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}

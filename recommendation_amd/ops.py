@@ -829,3 +829,14 @@ def bwd_prepare_noalloc(toffs, T, total_rows, indices, sorted_rows, perm, unique
     _lib.call('mi_embag_bwd_prepare_noalloc', _p(toffs), T, total_rows, _p(indices), _idx_bits(indices), _p(offsets),
               bag_len if offsets is None else 0, n_bags, n, _p(sorted_rows), _p(perm), _p(unique_rows),
               _p(seg_offsets), _p(counts), _stream())
+
+
+def stage_from_host(dst, src_pinned):
+    """dst (device) = src_pinned (pinned host tensor of the same byte size), copied by a kernel on the current stream
+    (mi_stage_from_host): orders with compute kernels on other streams without the host's help."""
+    if not dst.is_cuda or src_pinned.is_cuda or not src_pinned.is_pinned():
+        raise MiError("stage_from_host: dst must be a device tensor and src a pinned host tensor")
+    nbytes = dst.numel() * dst.element_size()
+    if nbytes != src_pinned.numel() * src_pinned.element_size() or not dst.is_contiguous() or not src_pinned.is_contiguous():
+        raise MiError("stage_from_host: contiguous tensors of the same byte size")
+    _lib.call('mi_stage_from_host', _p(dst), ctypes.c_void_p(src_pinned.data_ptr()), nbytes, _stream())
