@@ -241,7 +241,10 @@ def stage_report(fm, batches, reps, idx_bits, tms=None):
 
     if fused:
         # the two launches the step is made of (timed without advancing the schedule / with step size 0)
-        add('launch 1: forward + per-table LDS sort', fwd_sort, fwd_bytes + sort_bytes, 1)
+        # (the sort of launch 1 runs in LDS: the ids it reads are the forward's and its sorted rows + permutation
+        # are the only bytes it adds - 8 per entry; the radix-pass scratch counted for the stand-alone sort never
+        # reaches memory here)
+        add('launch 1: forward + per-table LDS sort', fwd_sort, fwd_bytes + B * T * 8, 1)
         add('launch 2: sparse update (segmented sum + fused %s) + dense side' % fm.opt, upd_dense,
             bwd_bytes + B * (nd + 2) * 4, 1)
     # the members on their own
