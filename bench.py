@@ -185,7 +185,7 @@ def stage_report(fm, batches, reps, idx_bits, tms=None):
     fm._buffers(batches[0][0])                 # the model's own loss / buffer set exist before the first step too
     saved = (fm.table.rec.clone(), fm.dp.clone(), fm.dm.clone(), fm.dv.clone(), fm.sched.clone())
     f32 = dict(dtype=torch.float32, device=fm.device)
-    fused = fm.fused and B <= ops.fm_fwd_sort_max_batch()
+    fused = fm._fused_ok(B, tms[0] if tms else None)
     sets, Us = [], []
     for j, (ids, dense, labels) in enumerate(batches):
         buf = dict(logit=torch.empty((B,), **f32), S=torch.empty((B, D), **f32), loss_rows=torch.empty((B,), **f32),
@@ -249,9 +249,11 @@ def stage_report(fm, batches, reps, idx_bits, tms=None):
             bwd_bytes + B * (nd + 2) * 4, 1)
     # the members on their own
     add('fm_fwd (gather+pool+interaction+loss)', fwd, fwd_bytes, 1)
-    lds_sort = B <= 8192
-    add('sort_by_row (%s)' % ('per-table LDS sort, 1 launch' if lds_sort else 'keygen + %d radix passes' % passes),
-        lambda j: sets[j][1].prepare(batches[j][0]), sort_bytes, 1 if lds_sort else 1 + 3 * passes)
+    lds_sort = B <= ops.fm_fwd_sort_max_batch()
+    one = B <= ops.fm_lds_sort_single_max()
+    add('sort_by_row (%s)' % (('per-table LDS sort, 1 launch' if one else 'ids to field-major + per-table LDS sort in parts')
+                              if lds_sort else 'keygen + %d radix passes' % passes),
+        lambda j: sets[j][1].prepare(batches[j][0]), sort_bytes, (1 if one else 2) if lds_sort else 1 + 3 * passes)
     add('fm_bwd_apply (segmented sum + fused %s)' % fm.opt, upd, bwd_bytes, 1)
     add('dense side (dwd/dbias + adam + mean loss)', dense_side, B * (nd + 2) * 4, 1)
     for dst, src in zip((fm.table.rec, fm.dp, fm.dm, fm.dv, fm.sched), saved):

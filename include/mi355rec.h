@@ -355,9 +355,11 @@ int mi_fm_dense_step(const float* g, const float* dense, int n_dense, int64_t B,
 
 /* mi_fm_fwd, the per-table sort of mi_embag_bwd_prepare (the form without run arrays) and,
  * when sched != NULL, mi_adam_schedule_step in ONE launch: the three need only the step's inputs,
- * so the launch lasts as long as the longest of them.  B <= mi_fm_fwd_sort_max_batch() (a table's
- * B entries are sorted in the LDS of one CU); sorted_rows[B*T], perm[B*T] as mi_embag_bwd_prepare
- * writes them.  Results are bit-identical to the separate calls.  ids_table_major != 0: ids is
+ * so the launch lasts as long as the longest of them.  B <= mi_fm_lds_sort_single_max() (8192: a
+ * table's B entries are sorted in the LDS of one to eight CUs) for ids in either layout; up to
+ * mi_fm_fwd_sort_max_batch() (131072) with table-major ids only - a larger table is shared by
+ * ceil(B / 4096) workgroups, each of which walks all the table's ids and sorts the entries between two
+ * cuts taken from 1024 samples.  sorted_rows[B*T], perm[B*T] as mi_embag_bwd_prepare writes them.  Results are bit-identical to the separate calls.  ids_table_major != 0: ids is
  * [T][B], one contiguous array per field - how the reference feeds its features, one tensor per
  * field (r_model.py:42-51) - instead of [B][T]; a table's ids are then read as whole lines by its
  * sort workgroups (one line per id otherwise); perm keeps the positions b*T + t either way.
@@ -365,6 +367,7 @@ int mi_fm_dense_step(const float* g, const float* dense, int n_dense, int64_t B,
  * that sorted this batch's ids earlier, beside the previous step's update (mi_embag_bwd_prepare on a
  * second stream: the sort needs nothing but the ids). */
 int mi_fm_fwd_sort_max_batch(void);
+int mi_fm_lds_sort_single_max(void);
 int mi_fm_fwd_sort(const mi_fm_table* tab, const int64_t* table_offsets, int T, const void* ids,
                    int idx_bits, int64_t B, const float* dense, int n_dense, const float* wd,
                    const float* bias, const float* labels, float gscale, float* logit, float* S,
@@ -373,7 +376,7 @@ int mi_fm_fwd_sort(const mi_fm_table* tab, const int64_t* table_offsets, int T, 
                    float beta2, int ids_table_major, void* stream);
 
 /* The sort of mi_fm_fwd_sort on its own (one launch, every table sorted in the LDS of one to four
- * CUs), for ids [B][T] or, with ids_table_major != 0, [T][B]; B <= mi_fm_fwd_sort_max_batch().  Same
+ * CUs), for ids [B][T] or, with ids_table_major != 0, [T][B]; the same limits on B.  Same
  * sorted_rows / perm, bit for bit.  The sort needs nothing but the ids, so a training loop that knows
  * its next batch issues this on a second stream beside the CURRENT step's update and leaves the step
  * itself with forward (mi_fm_fwd_sort without sort outputs) + update. */

@@ -117,6 +117,7 @@ _SIGNATURES = {
     'mi_din_lau_scatter': (c_int, [P, P, P, P, c_int64, P, c_int64, P, c_int64, c_int, c_int, P, P]),
     'mi_bce_logits': (c_int, [P, P, c_int64, c_float, P, P, P]),
     'mi_fm_fwd_sort_max_batch': (c_int, []),
+    'mi_fm_lds_sort_single_max': (c_int, []),
     'mi_fm_fwd_sort': (c_int, [POINTER(FmTable), P, c_int, P, c_int, c_int64, P, c_int, P, P, P, c_float, P, P, P, P,
                                P, c_int64, P, P, P, c_float, c_float, c_float, c_int, P]),
     'mi_fm_sort_ids': (c_int, [P, c_int, P, c_int, c_int64, c_int, c_int64, P, P, P]),

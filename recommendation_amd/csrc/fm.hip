@@ -88,7 +88,8 @@ int launch_fm(const FmFwdArgs& a, uint32_t sentinel, uint32_t* sorted_rows, uint
     else {                                                                                                          \
       const int fwd_blocks_ = (int) mi_cdiv(a.B, TS_THREADS / G_);                                                  \
       const int parts_ = mi_table_sort_parts(a.T, a.B, fwd_blocks_);                                                \
-      hipLaunchKernelGGL((fm_fwd_sort_kernel<IDX, D>), dim3((unsigned) (a.T * parts_ + fwd_blocks_)),               \
+      hipLaunchKernelGGL((fm_fwd_sort_kernel<IDX, D>),                                                              \
+                         dim3((unsigned) (mi_table_sort_blocks(a.T, a.B, parts_) + fwd_blocks_)),                   \
                          dim3(TS_THREADS), 0, s, a, fwd_blocks_, parts_, sentinel, sorted_rows, perm, sched, lr, b1, b2);        \
     }                                                                                                               \
     break;                                                                                                          \
@@ -175,7 +176,8 @@ extern "C" int mi_fm_fwd(const mi_fm_table* tab, const int64_t* table_offsets, i
   return launch_fm<int64_t>(a, 0u, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, s);
 }
 
-extern "C" int mi_fm_fwd_sort_max_batch(void) { return TS_MAX; }
+extern "C" int mi_fm_fwd_sort_max_batch(void) { return TS_BIG_MAX; }
+extern "C" int mi_fm_lds_sort_single_max(void) { return TS_MAX; }
 
 extern "C" int mi_fm_fwd_sort(const mi_fm_table* tab, const int64_t* table_offsets, int T, const void* ids,
                               int idx_bits, int64_t B, const float* dense, int n_dense, const float* wd,
@@ -187,9 +189,9 @@ extern "C" int mi_fm_fwd_sort(const mi_fm_table* tab, const int64_t* table_offse
   const int rc = check_fwd(who, tab, table_offsets, T, ids, idx_bits, B, dense, n_dense, wd, S);
   if (rc) return rc;
   MI_REQUIRE((sorted_rows != nullptr) == (perm != nullptr), "%s: sorted_rows and perm go together", who);
-  if (sorted_rows && (B < 1 || B > TS_MAX)) {
-    mi_set_error("%s: batch %lld outside 1..%d (one workgroup sorts a table in LDS); use mi_fm_fwd + "
-                 "mi_embag_bwd_prepare", who, (long long) B, TS_MAX);
+  if (sorted_rows && (B < 1 || B > TS_BIG_MAX || (B > TS_MAX && !ids_table_major))) {
+    mi_set_error("%s: batch %lld outside 1..%d (%d unless the ids are table-major: a large table's workgroups each walk "
+                 "all its ids); use mi_fm_fwd + mi_embag_bwd_prepare", who, (long long) B, TS_BIG_MAX, TS_MAX);
     return MI_ERR_UNSUPPORTED;
   }
   if (B == 0) return MI_OK;
@@ -211,9 +213,9 @@ extern "C" int mi_fm_sort_ids(const int64_t* table_offsets, int T, const void* i
   const char* who = "mi_fm_sort_ids";
   MI_REQUIRE(table_offsets && ids && sorted_rows && perm, "%s: null pointer", who);
   MI_REQUIRE(T >= 1 && (idx_bits == 32 || idx_bits == 64), "%s: bad T / idx_bits", who);
-  if (B < 1 || B > TS_MAX) {
-    mi_set_error("%s: batch %lld outside 1..%d (one workgroup sorts a table in LDS); use mi_embag_bwd_prepare", who,
-                 (long long) B, TS_MAX);
+  if (B < 1 || B > TS_BIG_MAX || (B > TS_MAX && !ids_table_major)) {
+    mi_set_error("%s: batch %lld outside 1..%d (%d unless the ids are table-major: a large table's workgroups each walk "
+                 "all its ids); use mi_embag_bwd_prepare", who, (long long) B, TS_BIG_MAX, TS_MAX);
     return MI_ERR_UNSUPPORTED;
   }
   if (total_rows < 1 || total_rows >= (int64_t) 0xFFFFFFFFll) {
@@ -221,13 +223,14 @@ extern "C" int mi_fm_sort_ids(const int64_t* table_offsets, int T, const void* i
     return MI_ERR_UNSUPPORTED;
   }
   const int parts = mi_table_sort_parts(T, (int) B, 0);
+  const unsigned grid = (unsigned) mi_table_sort_blocks(T, (int) B, parts);
   uint32_t* pv = reinterpret_cast<uint32_t*>(perm);
   hipStream_t s = (hipStream_t) stream;
   if (idx_bits == 32)
-    hipLaunchKernelGGL(fm_sort_kernel<int32_t>, dim3(T * parts), dim3(TS_THREADS), 0, s, table_offsets, T, ids, (int) B,
+    hipLaunchKernelGGL(fm_sort_kernel<int32_t>, dim3(grid), dim3(TS_THREADS), 0, s, table_offsets, T, ids, (int) B,
                        parts, (uint32_t) total_rows, sorted_rows, pv, ids_table_major ? 1 : 0);
   else
-    hipLaunchKernelGGL(fm_sort_kernel<int64_t>, dim3(T * parts), dim3(TS_THREADS), 0, s, table_offsets, T, ids, (int) B,
+    hipLaunchKernelGGL(fm_sort_kernel<int64_t>, dim3(grid), dim3(TS_THREADS), 0, s, table_offsets, T, ids, (int) B,
                        parts, (uint32_t) total_rows, sorted_rows, pv, ids_table_major ? 1 : 0);
   MI_LAUNCH_CHECK();
   return MI_OK;

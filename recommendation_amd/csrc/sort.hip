@@ -432,11 +432,25 @@ __global__ __launch_bounds__(TS_THREADS) void table_sort_kernel(const int64_t* _
                                                                const void* __restrict__ indices, int bag_len,
                                                                int n, int parts, uint32_t sentinel,
                                                                uint32_t* __restrict__ sorted_rows,
-                                                               uint32_t* __restrict__ perm) {
+                                                               uint32_t* __restrict__ perm, int ids_tm) {
   int t, part, np;
   if (!ts_assign(toffs, T, n, parts, (int) blockIdx.x, t, part, np)) return;
   table_sort_body<IDX>(t, part, np, toffs, T, indices, bag_len, n, sentinel,
-                       sorted_rows, perm);
+                       sorted_rows, perm, ids_tm != 0);
+}
+
+// Fixed-width bags, sample-major ids [n_bags / T][T][bag_len] -> int32 ids table-major [T][per_table] (entry e of a
+// table: its e-th (sample, position-in-bag) pair).  Ids outside int32 become -1: outside every table.
+template <typename IDX>
+__global__ __launch_bounds__(256) void ids_table_major_kernel(const void* __restrict__ indices, int T, int bag_len,
+                                                             int per_table, int n, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int per_sample = T * bag_len;
+  const int b = i / per_sample, rem = i - b * per_sample;
+  const int t = rem / bag_len, j = rem - t * bag_len;
+  const int64_t id = mi_ld_id<IDX>(indices, (int64_t) i);
+  out[(size_t) t * per_table + (size_t) b * bag_len + j] = (id >= 0 && id <= 0x7FFFFFFFll) ? (int32_t) id : -1;
 }
 
 int bit_width_u64(uint64_t v) {
@@ -496,17 +510,32 @@ extern "C" int mi_embag_bwd_prepare(const int64_t* table_offsets, int T, int64_t
   const int n = (int) n_entries;
   const SortWs ws = carve(workspace, n_entries);
   const uint32_t sentinel = (uint32_t) total_rows;  // greater than every valid row
-  if (!want_runs && !offsets && n / T <= TS_MAX) {
-    // fixed-width bags, few enough entries per table: one launch, every table sorted in LDS.
+  if (!want_runs && !offsets && n / T <= TS_BIG_MAX) {
+    // fixed-width bags, few enough entries per table: every table sorted in LDS by one launch.
     // (Only without run arrays: padding entries then end each table's block, not the array.)
     const int per_table = n / T;
     const int parts = mi_table_sort_parts(T, per_table, 0);
-    if (idx_bits == 32)
-      hipLaunchKernelGGL(table_sort_kernel<int32_t>, dim3(T * parts), dim3(TS_THREADS), 0, s, table_offsets, T,
-                         indices, bag_len, per_table, parts, sentinel, sorted_rows, reinterpret_cast<uint32_t*>(perm));
-    else
-      hipLaunchKernelGGL(table_sort_kernel<int64_t>, dim3(T * parts), dim3(TS_THREADS), 0, s, table_offsets, T,
-                         indices, bag_len, per_table, parts, sentinel, sorted_rows, reinterpret_cast<uint32_t*>(perm));
+    const unsigned grid = (unsigned) mi_table_sort_blocks(T, per_table, parts);
+    uint32_t* pv = reinterpret_cast<uint32_t*>(perm);
+    if (per_table > TS_MAX && T > 1) {
+      // a table's parts each walk all its ids, twice: a launch before lays them out table by table (int32) so that
+      // the walks read whole lines instead of one line per id
+      int32_t* tm = reinterpret_cast<int32_t*>(ws.keys_alt);
+      if (idx_bits == 32)
+        hipLaunchKernelGGL(ids_table_major_kernel<int32_t>, dim3((unsigned) mi_cdiv(n, 256)), dim3(256), 0, s, indices,
+                           T, bag_len, per_table, n, tm);
+      else
+        hipLaunchKernelGGL(ids_table_major_kernel<int64_t>, dim3((unsigned) mi_cdiv(n, 256)), dim3(256), 0, s, indices,
+                           T, bag_len, per_table, n, tm);
+      hipLaunchKernelGGL(table_sort_kernel<int32_t>, dim3(grid), dim3(TS_THREADS), 0, s, table_offsets, T, tm, bag_len,
+                         per_table, parts, sentinel, sorted_rows, pv, 1);
+    } else if (idx_bits == 32) {
+      hipLaunchKernelGGL(table_sort_kernel<int32_t>, dim3(grid), dim3(TS_THREADS), 0, s, table_offsets, T, indices,
+                         bag_len, per_table, parts, sentinel, sorted_rows, pv, T == 1 ? 1 : 0);  // (one table: its ids are one run already)
+    } else {
+      hipLaunchKernelGGL(table_sort_kernel<int64_t>, dim3(grid), dim3(TS_THREADS), 0, s, table_offsets, T, indices,
+                         bag_len, per_table, parts, sentinel, sorted_rows, pv, T == 1 ? 1 : 0);  // (one table: its ids are one run already)
+    }
     MI_LAUNCH_CHECK();
     return MI_OK;
   }

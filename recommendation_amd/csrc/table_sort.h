@@ -31,6 +31,11 @@ constexpr int TS_ITEMS = 8;
 constexpr int TS_MAX = TS_THREADS * TS_ITEMS;  // 8192 entries per table
 constexpr int TS_RADIX = 256;
 constexpr int TS_PARTS_MAX = 8;
+// Tables of more than TS_MAX entries are shared by ceil(n / TS_BIG_PART) workgroups, each of which walks all the
+// table's ids twice (count, then fill) and sorts its share of about TS_BIG_PART entries: see table_sort_big_body.
+constexpr int TS_BIG_MAX = 128 * 1024;  // entries per table (positions take 17 bits of the 64-bit order word)
+constexpr int TS_BIG_PART = 4096;
+constexpr int TS_XCDS = 8;
 
 // How many workgroups are launched per table: up to TS_PMAX once a table has enough entries to make
 // sharing worth its extra pass over the ids.  Only tables of more than 65535 rows use them all (see
@@ -41,9 +46,15 @@ constexpr int TS_PARTS_MAX = 8;
 #define TS_PMAX 8
 #endif
 static inline int mi_table_sort_parts(int T, int per_table, int other_blocks) {
+  if (per_table > TS_MAX) return (per_table + TS_BIG_PART - 1) / TS_BIG_PART;  // at most 32
   int parts = per_table >= 4096 ? TS_PMAX : (per_table >= 2048 ? 2 : 1);
   while (parts > 1 && T * parts / 2 + other_blocks > 248) parts >>= 1;
   return parts;
+}
+
+// Sort workgroups a launch needs (see ts_assign for how they are dealt to tables).
+static inline int mi_table_sort_blocks(int T, int per_table, int parts) {
+  return per_table > TS_MAX ? (T + TS_XCDS - 1) / TS_XCDS * TS_XCDS * parts : T * parts;
 }
 
 // The LDS arrays of a sorting workgroup (152 KB: one workgroup per CU).
@@ -187,6 +198,21 @@ __device__ __forceinline__ int ts_lds_sort(TsLds& L, int m, int passes, int cur)
 // round trip for the offsets and a wave scan, instead of a loop of T dependent scalar loads.
 __device__ __forceinline__ bool ts_assign(const int64_t* __restrict__ toffs, int T, int n, int parts_max, int slot,
                                           int& t_out, int& part_out, int& parts_out) {
+  if (n > TS_MAX) {
+    // Every part of a large table walks all the table's ids: the parts of one table go to workgroups that share an
+    // XCD (workgroups are dealt to the XCDs round robin, so slots of equal index mod 8 sit on one), whose L2 then
+    // serves all but the first walk.  Table t belongs to XCD t mod 8; the launch has ceil(T / 8) * 8 * parts slots.
+#ifdef TS_BIG_MAP_LINEAR
+    t_out = slot / parts_max;
+    part_out = slot % parts_max;
+#else
+    const int r = slot % TS_XCDS, idx = slot / TS_XCDS;
+    t_out = (idx / parts_max) * TS_XCDS + r;
+    part_out = idx % parts_max;
+#endif
+    parts_out = parts_max;
+    return t_out < T;
+  }
   const int lane = threadIdx.x & (MI_WAVE - 1);
   int base = 0;
   for (int t0 = 0; t0 < T; t0 += MI_WAVE) {  // lane l looks at table t0 + l
@@ -209,6 +235,223 @@ __device__ __forceinline__ bool ts_assign(const int64_t* __restrict__ toffs, int
   return false;
 }
 
+// Part `part` of `parts` of a table of TS_MAX < n <= TS_BIG_MAX entries whose ids lie TABLE-MAJOR (the table's n
+// ids one contiguous run: entry e at indices[t * n + e]).  The scheme of table_sort_body with three changes.
+// (1) 1024 samples, one per thread, at evenly spaced positions each shifted by a fixed pseudo-random amount (ids
+// that repeat with the period of the spacing would otherwise all show the same key); they are ranked by sorting
+// them with the LDS sort itself.  (2) The ids do not fit the registers, so they are walked twice - once to count
+// the entries between the part's two cuts and those below, once to move the selected ones into LDS in table
+// order; wave w walks the w-th sixteenth of the table.  (3) Whatever the data, a part holds more than TS_MAX
+// entries only if the samples misjudge it badly; it then halves its range of the order (key, position) until the
+// count fits, sorts that, and goes on with the rest of its range - slower, never wrong.
+//
+// A walk of 65536 ids takes one workgroup about 18 us whatever else runs on the chip (a single CU streams some
+// 30 GB/s this way), which is most of the part's time; an entry costs as little else as possible: one load at a constant offset from the lane's pointer, one range check, and two compares
+// against thresholds that are the same for the whole wave - the order (key, position) against a cut (K, P) is
+// key >= K + 1 for the 64 entries of a round that all lie before P and key >= K for a round that lies behind it;
+// only the one round that contains P compares per lane.
+template <typename IDX>
+__device__ __forceinline__ void table_sort_big_body(TsLds& L, int t, int part, int parts,
+                                                    const int64_t* __restrict__ toffs, int T,
+                                                    const void* __restrict__ indices, int bag_len, int n,
+                                                    uint32_t sentinel, uint32_t* __restrict__ sorted_rows,
+                                                    uint32_t* __restrict__ perm) {
+  auto& kbuf = L.kbuf;
+  auto& vbuf = L.vbuf;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  TS_MARK(0);
+  const int64_t base_row = toffs[t];
+  const uint32_t rows = (uint32_t) (toffs[t + 1] - base_row);
+  const IDX* __restrict__ tab_ids = reinterpret_cast<const IDX*>(indices) + (int64_t) t * n;
+  auto key_of_id = [&](IDX id) {  // an id outside [0, rows) sorts behind every row
+    if constexpr (sizeof(IDX) == 8) return (unsigned long long) id < (unsigned long long) rows ? (uint32_t) id : rows;
+    else return (uint32_t) id < rows ? (uint32_t) id : rows;
+  };
+  const int wspan = (n + TS_WAVES * MI_WAVE - 1) / (TS_WAVES * MI_WAVE) * MI_WAVE;  // entries of a wave, whole 64s
+  const int w_lo = w * wspan, w_hi = w_lo + wspan < n ? w_lo + wspan : n;
+  const int stride = n / TS_THREADS;  // >= 8
+  auto sample_pos = [&](int i) {
+    uint32_t h = (uint32_t) i * 2654435761u;
+    h ^= h >> 15;
+    return i * stride + (int) (((h >> 8) * (uint32_t) stride) >> 24);  // stride <= 128: the product fits 32 bits
+  };
+  int all_bits = 0;
+  for (uint32_t v = rows; v; v >>= 1) ++all_bits;  // keys 0..rows
+  kbuf[0][tid] = key_of_id(tab_ids[sample_pos(tid)]);
+  vbuf[0][tid] = (uint32_t) tid;
+  {
+    // ascending sample index is ascending position: the stable sort by key is the order (key, position)
+    const int sc = ts_lds_sort_bits(L, TS_THREADS, all_bits, 0);
+    const unsigned long long top = (unsigned long long) (rows + 1u) << 17;  // above every entry's order word
+    if (tid < 2) {
+      const int q = part + tid;
+      unsigned long long c = tid == 0 ? 0ull : top;
+      if (q > 0 && q < parts) {
+        const int at = q * TS_THREADS / parts;
+        c = ((unsigned long long) kbuf[sc][at] << 17) | (unsigned long long) sample_pos((int) vbuf[sc][at]);
+      }
+      L.cut64[tid] = c;
+    }
+  }
+  __syncthreads();
+  TS_MARK(1);
+  const unsigned long long hi = L.cut64[1];
+  unsigned long long cur_lo = L.cut64[0];
+#ifndef TS_BIG_WALK
+#define TS_BIG_WALK 16
+#endif
+  constexpr int WALK = TS_BIG_WALK;  // entries per lane and round
+  // a lane's slot beyond the wave's share: a key above every threshold (rows + 1 <= 2^32 - 1 is the highest), so
+  // it is neither selected nor counted as below
+  constexpr uint32_t TS_NO_ENTRY = 0xFFFFFFFFu;
+  // A round is WALK * 64 consecutive entries from r0, read as WALK / PER groups of 64 * PER entries: in a group
+  // lane l holds the PER consecutive entries from r0 + (group * 64 + l) * PER - one 16-byte load where the table's
+  // ids are aligned to that and the round lies inside the wave's share (four times fewer memory instructions than
+  // one id per load; the walk is bound by those), single loads otherwise.  (Slots past the share re-read the
+  // share's first entry: no branch between the loads.)
+  constexpr int PER = 16 / (int) sizeof(IDX), GROUPS = WALK / PER;
+  const bool wide_ok = ((uintptr_t) tab_ids & 15) == 0;  // (w_lo and the rounds' starts are multiples of 64 entries)
+  auto load_round = [&](int r0, uint32_t* key) {
+    if (wide_ok && r0 + WALK * MI_WAVE <= w_hi) {  // uniform
+      const uint4* __restrict__ p = reinterpret_cast<const uint4*>(tab_ids + r0) + lane;
+      uint4 raw[GROUPS];
+#pragma unroll
+      for (int g = 0; g < GROUPS; ++g) raw[g] = p[g * MI_WAVE];
+#pragma unroll
+      for (int g = 0; g < GROUPS; ++g) {
+        if constexpr (sizeof(IDX) == 4) {
+          key[g * PER + 0] = key_of_id((IDX) raw[g].x);
+          key[g * PER + 1] = key_of_id((IDX) raw[g].y);
+          key[g * PER + 2] = key_of_id((IDX) raw[g].z);
+          key[g * PER + 3] = key_of_id((IDX) raw[g].w);
+        } else {
+          key[g * PER + 0] = key_of_id((IDX) (((unsigned long long) raw[g].y << 32) | raw[g].x));
+          key[g * PER + 1] = key_of_id((IDX) (((unsigned long long) raw[g].w << 32) | raw[g].z));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < WALK; ++k) {
+        const int e = r0 + ((k / PER) * MI_WAVE + lane) * PER + (k % PER);
+        const uint32_t kk = key_of_id(tab_ids[e < w_hi ? e : w_lo]);
+        key[k] = e < w_hi ? kk : TS_NO_ENTRY;
+      }
+    }
+  };
+  for (;;) {  // uniform: one turn unless the part had to be narrowed
+    unsigned long long cur_hi = hi;
+    uint32_t wave_first;
+    int m, below;
+    for (;;) {  // uniform
+      uint32_t nsel = 0, nbelow = 0;
+      const uint32_t klo = (uint32_t) (cur_lo >> 17), khi = (uint32_t) (cur_hi >> 17);
+      const int plo = (int) (cur_lo & 0x1FFFFull), phi = (int) (cur_hi & 0x1FFFFull);
+      for (int r0 = w_lo; r0 < w_hi; r0 += WALK * MI_WAVE) {
+        uint32_t key[WALK];
+        load_round(r0, key);
+#pragma unroll
+        for (int k = 0; k < WALK; ++k) {
+          const int g0 = r0 + (k / PER) * MI_WAVE * PER, g1 = g0 + MI_WAVE * PER;  // the group's entries (uniform)
+          // (per-lane counters, added up once behind the walk: masks counted on the scalar unit made every entry
+          // wait for a compare to cross over to it)
+          uint32_t tlo, thi;
+          if ((g0 >= plo || g1 <= plo) && (g0 >= phi || g1 <= phi)) {  // uniform: no cut inside the group
+            tlo = klo + (g0 < plo ? 1u : 0u);
+            thi = khi + (g0 < phi ? 1u : 0u);
+          } else {
+            const int e = g0 + lane * PER + (k % PER);
+            tlo = klo + (e < plo ? 1u : 0u);
+            thi = khi + (e < phi ? 1u : 0u);
+          }
+          // tlo <= thi, so tlo <= key < thi is one unsigned compare (and never holds for TS_NO_ENTRY)
+          nsel += (key[k] - tlo < thi - tlo) ? 1u : 0u;
+          nbelow += key[k] < tlo ? 1u : 0u;
+        }
+      }
+      nsel = __builtin_amdgcn_readlane((int) ts_wave_scan(nsel), MI_WAVE - 1);
+      nbelow = __builtin_amdgcn_readlane((int) ts_wave_scan(nbelow), MI_WAVE - 1);
+      __syncthreads();  // (the previous turn's readers of wsel and of the key images are done)
+      if (lane == 0) {
+        L.wsel[w][0] = nsel;
+        L.wsel[w][1] = nbelow;
+      }
+      __syncthreads();
+      const uint32_t a_sel = lane < TS_WAVES ? L.wsel[lane][0] : 0u, a_below = lane < TS_WAVES ? L.wsel[lane][1] : 0u;
+      const uint32_t i_sel = ts_wave_scan(a_sel), i_below = ts_wave_scan(a_below);
+      wave_first = (uint32_t) __builtin_amdgcn_readlane((int) (i_sel - a_sel), w);
+      m = __builtin_amdgcn_readlane((int) i_sel, MI_WAVE - 1);
+      below = __builtin_amdgcn_readlane((int) i_below, MI_WAVE - 1);
+      TS_MARK(2);
+      if (m <= TS_MAX) break;
+      cur_hi = cur_lo + (cur_hi - cur_lo) / 2;  // order words are distinct: a range of one word holds one entry
+    }
+    const uint32_t key_lo = (uint32_t) (cur_lo >> 17);
+    const uint32_t key_hi = (uint32_t) (cur_hi >> 17);
+    const uint32_t span = (key_hi < rows ? key_hi : rows) - key_lo;
+    int bits = 0;
+    for (uint32_t v = span; v; v >>= 1) ++bits;
+    uint32_t run = wave_first;
+    const int plo = (int) (cur_lo & 0x1FFFFull), phi = (int) (cur_hi & 0x1FFFFull);
+    for (int r0 = w_lo; r0 < w_hi; r0 += WALK * MI_WAVE) {
+      uint32_t key[WALK];
+      load_round(r0, key);
+#pragma unroll
+      for (int g = 0; g < GROUPS; ++g) {
+        // the group's selected entries go to LDS in entry order: lanes in order, a lane's PER entries in order
+        const int g0 = r0 + g * MI_WAVE * PER, g1 = g0 + MI_WAVE * PER;
+        const int e_first = g0 + lane * PER;
+        const bool plain = (g0 >= plo || g1 <= plo) && (g0 >= phi || g1 <= phi);  // uniform: no cut inside the group
+        bool sel[PER];
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+          const uint32_t kk = key[g * PER + j];
+          const uint32_t tlo = key_lo + ((plain ? g0 : e_first + j) < plo ? 1u : 0u);
+          const uint32_t thi = key_hi + ((plain ? g0 : e_first + j) < phi ? 1u : 0u);
+          sel[j] = kk - tlo < thi - tlo;  // tlo <= kk < thi (tlo <= thi)
+          c += sel[j] ? 1u : 0u;
+        }
+        if (__builtin_amdgcn_ballot_w64(c != 0)) {  // uniform
+          const uint32_t incl = ts_wave_scan(c);
+          uint32_t d = run + incl - c;
+#pragma unroll
+          for (int j = 0; j < PER; ++j) {
+            if (sel[j]) {
+              kbuf[0][d] = key[g * PER + j] - key_lo;
+              vbuf[0][d] = (uint32_t) (e_first + j);  // the entry's number; its place among the ids is worked out at the end
+              ++d;
+            }
+          }
+          run += (uint32_t) __builtin_amdgcn_readlane((int) incl, MI_WAVE - 1);
+        }
+      }
+    }
+    TS_MARK(3);
+    const int cur = ts_lds_sort_bits(L, m, bits, 0);  // (its first barrier makes the fill visible)
+    const size_t out = (size_t) t * n + below;
+    const float inv_len = __builtin_amdgcn_rcpf((float) bag_len);
+#pragma unroll
+    for (int k = 0; k < TS_ITEMS; ++k) {
+      const int i = k * TS_THREADS + tid;
+      if (i < m) {
+        const uint32_t lk = kbuf[cur][i] + key_lo;
+        sorted_rows[out + i] = lk < rows ? (uint32_t) (base_row + lk) : sentinel;
+        // where entry e's id lies in a SAMPLE-major id array (what perm holds whichever layout was read; the
+        // division as in table_sort_body, whose bound on the rounding holds for e < 2^17 as well)
+        const int e = (int) vbuf[cur][i];
+        const int b = (int) (((float) e + 0.5f) * inv_len);
+        perm[out + i] = (uint32_t) ((b * T + t) * bag_len + (e - b * bag_len));
+      }
+    }
+    TS_MARK(8);
+#ifdef TS_TRACE
+    if (threadIdx.x == 0) { ts_trace_buf[blockIdx.x * 16 + 9] = (unsigned long long) bits; ts_trace_buf[blockIdx.x * 16 + 10] = (unsigned long long) m; }
+#endif
+    if (cur_hi >= hi) break;
+    cur_lo = cur_hi;
+  }
+}
+
 // Part `part` of `parts` of table `t` is sorted by the calling workgroup (all TS_THREADS threads
 // take part).
 template <typename IDX>
@@ -217,6 +460,10 @@ __device__ __forceinline__ void table_sort_body(int t, int part, int parts, cons
                                                 uint32_t sentinel, uint32_t* __restrict__ sorted_rows,
                                                 uint32_t* __restrict__ perm, bool ids_tm = false) {
   __shared__ TsLds L;
+  if (n > TS_MAX) {  // uniform
+    table_sort_big_body<IDX>(L, t, part, parts, toffs, T, indices, bag_len, n, sentinel, sorted_rows, perm);  // (table-major ids: the host checks)
+    return;
+  }
   auto& kbuf = L.kbuf;
   auto& vbuf = L.vbuf;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

@@ -63,6 +63,9 @@ class FactorizationMachine(object):
         self._cur = 0                          # which of the two plans of a buffer set holds it
         self.fused = True                      # set False to run the step as five separate launches
         self._fused_max = ops.fm_fwd_sort_max_batch()
+        # beyond this many samples a table is sorted by several workgroups that each walk all its ids: only with the
+        # ids also given field-major (``ids_tm``)
+        self._fused_any_layout_max = ops.fm_lds_sort_single_max()
 
     # -- views ------------------------------------------------------------------------------
     @property
@@ -147,6 +150,9 @@ class FactorizationMachine(object):
         main.wait_stream(side)
         self.plan = plan
 
+    def _fused_ok(self, B, ids_tm):
+        return self.fused and (B <= self._fused_any_layout_max or (ids_tm is not None and B <= self._fused_max))
+
     def _step_body(self, ids, dense, labels, streams=None, ids_tm=None):
         """The launches of one step.  With ``streams`` (two side streams, used under graph capture)
         the sort runs beside the forward - it only needs the ids - and the dense-side update beside
@@ -154,7 +160,7 @@ class FactorizationMachine(object):
         main = torch.cuda.current_stream()
         adam = self.opt == 'adam_tf'
         B = ids.shape[0]
-        if self.fused and B <= self._fused_max:
+        if self._fused_ok(B, ids_tm):
             # two launches: {schedule, forward, sort} and {sparse update, dense side}
             r = ops.fm_fwd_sort(self.table, self.toffs, ids, self.plan, dense if self.n_dense else None,
                                 self.wd if self.n_dense else None, self.bias, labels, 1.0 / B, self.err,
@@ -205,7 +211,7 @@ class FactorizationMachine(object):
         bit-identical to the step without ``next_ids``."""
         self._buffers(ids)
         B = ids.shape[0]
-        pre = next_ids is not None and self.fused and B <= self._fused_max
+        pre = next_ids is not None and self._fused_ok(B, ids_tm) and self._fused_ok(B, next_ids_tm)
         if pre:
             if tuple(next_ids.shape) != tuple(ids.shape) or next_ids.dtype != ids.dtype:
                 raise ops.MiError("train_step: next_ids must have the shape and dtype of ids")

@@ -484,6 +484,11 @@ def fm_fwd_sort_max_batch():
     return int(_lib.load().mi_fm_fwd_sort_max_batch())
 
 
+def fm_lds_sort_single_max():
+    """Largest batch whose per-table sort takes ids in either layout (beyond it: field-major ids only)."""
+    return int(_lib.load().mi_fm_lds_sort_single_max())
+
+
 def fm_fwd_sort(table, toffs, ids, plan, dense=None, wd=None, bias=None, labels=None, gscale=1.0, err=None, out=None,
                 sched=None, lr=0.0, beta1=0.9, beta2=0.999, ids_tm=None):
     """fm_fwd + the sort of ``plan`` (built without run arrays for ids of this shape) + one optimizer

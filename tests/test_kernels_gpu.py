@@ -710,6 +710,124 @@ def test_per_table_lds_sort_with_hot_neighbouring_ids_in_a_table_of_2_pow_27_row
     assert np.array_equal(plan.perm.cpu().numpy(), want_perm)
 
 
+def _sample_positions(n):
+    """Where the large-table sort takes its 1024 samples (csrc/table_sort.h: evenly spaced, each shifted by a fixed
+    pseudo-random amount below the spacing)."""
+    stride = n // 1024
+    i = np.arange(1024, dtype=np.uint64)
+    h = (i * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    return (i * np.uint64(stride) + (((h >> np.uint64(8)) * np.uint64(stride)) >> np.uint64(24))).astype(np.int64)
+
+
+def _check_sorted_plan(plan, toffs, T, ids, L):
+    total = int(toffs[-1])
+    want_rows, want_perm, _, _ = oe.prepare(toffs, T, ids, bag_len=L)
+    got_rows = plan.sorted_rows.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    got_perm = plan.perm.cpu().numpy()
+    per_table = got_rows.size // T
+    blocks = got_rows.reshape(T, per_table)
+    for t in range(T):                     # padding closes each table's block
+        nv = int((blocks[t] != total).sum())
+        assert (blocks[t][:nv] != total).all() and (blocks[t][nv:] == total).all()
+    keep = got_rows != total
+    assert np.array_equal(got_rows[keep], want_rows)
+    assert np.array_equal(got_perm[keep], want_perm)
+    # the padding entries' positions are the remaining ones, each once
+    assert np.array_equal(np.sort(got_perm), np.arange(got_perm.size))
+
+
+@pytest.mark.parametrize("B,L,idt", [(65536, 1, np.int64), (20000, 3, np.int32), (131072, 1, np.int32), (8193, 1, np.int64),
+                                     (30011, 1, np.int32)])
+@pytest.mark.parametrize("kind", ["uniform", "padded", "one_row", "period_of_the_sample_spacing"])
+def test_large_table_lds_sort_in_parts_is_the_global_stable_sort(dev, B, L, idt, kind):
+    """More than 8192 entries per table: ceil(n / 4096) workgroups share a table, each sorting the entries between
+    two cuts taken from 1024 samples.  Bit for bit numpy's stable argsort by (row, position), from sample-major ids
+    (mi_embag_bwd_prepare: a launch lays them out table by table first) - with out-of-range ids, with every id equal
+    (the cuts then divide by position alone) and with ids that repeat with the period of the sample spacing."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(17)
+    rows = [3, 1000, 10131227, 24, 1 << 27]
+    T = len(rows)
+    toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    n = B * L
+    cols = []
+    for r in rows:
+        if kind == "one_row":
+            col = np.full((B, L), r - 1)
+        elif kind == "period_of_the_sample_spacing":
+            col = (np.arange(n) % (n // 1024)).reshape(B, L) % r
+        else:
+            col = rng.integers(0, r, size=(B, L))
+        if kind == "padded":
+            bad = rng.random((B, L)) < 0.2
+            col[bad] = np.where(rng.random(int(bad.sum())) < 0.5, -1, r + 5)
+        cols.append(col)
+    ids = np.stack(cols, axis=1).astype(idt)
+    plan = ops.SortedPlan(torch.from_numpy(toffs).to(dev), T, int(toffs[-1]), torch.from_numpy(ids).to(dev),
+                          bag_len=L, runs=False)
+    _check_sorted_plan(plan, toffs, T, ids, L)
+
+
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+def test_large_table_sort_narrows_a_part_the_samples_misjudged(dev, idt):
+    """Ids chosen against the sampling: the sampled positions hold keys spread over the whole table, every other
+    position holds row 0.  The first part then receives nearly the whole table - more than a workgroup's LDS holds -
+    and must halve its range of the (row, position) order until the count fits, part after part.  Field-major ids
+    through mi_fm_sort_ids; same bits as the stable argsort."""
+    from recommendation_amd import ops
+    B, rows = 65536, [1 << 20, 50]
+    T = len(rows)
+    toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    pos = _sample_positions(B)
+    assert np.unique(pos).size == 1024 and pos.max() < B
+    col0 = np.zeros(B, dtype=np.int64)
+    col0[pos] = 1 + np.arange(1024) * 1000
+    col1 = np.zeros(B, dtype=np.int64)
+    col1[pos] = np.arange(1024) % 50
+    ids = np.stack([col0, col1], axis=1).astype(idt)
+    d_ids = torch.from_numpy(ids).to(dev)
+    plan = ops.SortedPlan(torch.from_numpy(toffs).to(dev), T, int(toffs[-1]), d_ids, bag_len=1, runs=False)
+    plan.sorted_rows.fill_(0)
+    plan.perm.fill_(0)
+    ops.fm_sort_ids(torch.from_numpy(toffs).to(dev), d_ids, plan, ids_tm=d_ids.t().contiguous())
+    _check_sorted_plan(plan, toffs, T, ids[:, :, None], 1)
+    with pytest.raises(ops.MiError):
+        ops.fm_sort_ids(torch.from_numpy(toffs).to(dev), d_ids, plan)      # sample-major ids: only up to 8192
+
+
+@pytest.mark.parametrize("opt", ["adagrad_rowwise", "adam_tf"])
+def test_fm_two_launch_step_at_batch_65536_equals_the_five_launch_step_bitwise(dev, opt):
+    """Field-major ids at a batch beyond one workgroup's LDS: {schedule, forward, sort in parts} + {update, dense side}
+    leave the bits of the five separate launches (whose sort goes through mi_embag_bwd_prepare), eager and replayed."""
+    from recommendation_amd.fm import FactorizationMachine
+    rows = [1460, 583, 300000, 305, 24, 3, 10, 4, 18, 15, 105, 27, 2173]
+    B = 65536
+    ref = ofm.State(rows, 16, 13, seed=7, opt=opt)
+    models = [FactorizationMachine(rows, 16, 13, device=dev, opt=opt, lr=1e-2) for _ in range(3)]
+    for m in models:
+        m.load_state(ref)
+    bufs = tm = None
+    for step in range(2):
+        arrs = ofm.synthetic_batch(B, rows, 13, seed=90 + step, dist='zipf')
+        if bufs is None:
+            bufs = tuple(torch.from_numpy(x).to(dev) for x in arrs)
+            tm = bufs[0].t().contiguous()
+        else:
+            for dst, src in zip(bufs, arrs):
+                dst.copy_(torch.from_numpy(src))
+            tm.copy_(bufs[0].t())
+        l0 = models[0].train_step(*bufs).clone()                          # no field-major ids: five launches
+        l1 = models[1].train_step(*bufs, ids_tm=tm).clone()
+        l2 = models[2].train_step(*bufs, ids_tm=tm, graph=True).clone()
+        assert torch.equal(l0, l1) and torch.equal(l0, l2)
+        assert torch.equal(models[0].plan.sorted_rows, models[1].plan.sorted_rows)
+        assert torch.equal(models[0].plan.perm, models[1].plan.perm)
+    for m in models[1:]:
+        assert torch.equal(models[0].table.rec, m.table.rec)
+        assert torch.equal(models[0].dp, m.dp) and torch.equal(models[0].sched, m.sched)
+
+
 def test_fm_record_layout_is_checked(dev):
     from recommendation_amd import ops
     t = ops.FmRecords(10, 16, ops.MI_OPT_ADAM_TF, dev)
