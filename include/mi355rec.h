@@ -721,6 +721,108 @@ int mi_din_w1_step(const float* slab, int n_slabs, int64_t slab_stride, const fl
                    float beta1, float beta2, float eps, void* Wf, void* WfT, float* Wq, float* WqT,
                    float* grad_out, void* stream);
 
+/* out[m][n] = a[m][n] * b[m][n], bf16, n < N (N % 8 == 0): the product a CROSS_BWD epilogue would have stored
+ * when the producer of `a` is not one of this library's contractions. */
+int mi_mul_bf16(const void* a, int64_t ld_a, const void* b, int64_t ld_b, int64_t M, int N, void* out,
+                int64_t ld_out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Whole-network entry points: the launch sequences of the two interaction models behind one call each
+ * way, for hosts that are not Python.  Not in the reference (its network is r_model.py:52-58); they stand
+ * for what a maintainer would register as ONE operator per direction.  Every step inside is one of the
+ * entry points above, in the order recommendation_amd/dcn.py and din.py issue them: same bits.
+ *
+ * A dense parameter carries tf.train.AdamOptimizer's state (model_trainer.py:157): fp32 master w with
+ * m, v; matrices also their bf16 working copy [rows][cols] and its transpose [cols][rows], both
+ * refreshed by the backward call.  grad_out (optional) receives the gradient.
+ * ---------------------------------------------------------------------------------- */
+typedef struct mi_adam_param {
+  float* w;
+  float* m;
+  float* v;
+  void* w_bf16;   /* matrices only */
+  void* w_bf16_t; /* matrices only */
+  float* grad_out;
+} mi_adam_param;
+
+#define MI_CROSS_MAX_LAYERS 8
+/* DCN-v2 cross network: x_{l+1} = x0 * (x_l W_l^T + b_l) + x_l, rows of `width` bf16 values (a multiple of
+ * 64, zero padded), W_l [width][width], b_l [width]. */
+typedef struct mi_cross_net {
+  int n_layers, width;
+  mi_adam_param W[MI_CROSS_MAX_LAYERS];
+  mi_adam_param b[MI_CROSS_MAX_LAYERS];
+} mi_cross_net;
+
+/* Workspace (256-byte aligned) shared by the two calls of a step: x_1..x_L, u_0..u_{L-1} (written by the
+ * forward, read by the backward), dx_0..dx_L, two du buffers, fp32 reduction slabs.  mi_cross_workspace_part
+ * gives offset and size of one of them, for a caller that feeds or reads them in place:
+ * MI_CROSS_PART_X index 1..L, _U 0..L-1, _DX 0..L, _DU 0..1, _SLAB 0. */
+#define MI_CROSS_PART_X 0
+#define MI_CROSS_PART_U 1
+#define MI_CROSS_PART_DX 2
+#define MI_CROSS_PART_DU 3
+#define MI_CROSS_PART_SLAB 4
+size_t mi_cross_workspace_bytes(int64_t B, int width, int n_layers);
+int mi_cross_workspace_part(int64_t B, int width, int n_layers, int what, int index, size_t* offset,
+                            size_t* bytes);
+
+/* Forward over x0 [B][ld] bf16 (B a multiple of 64): L launches; *x_last = x_L inside the workspace. */
+int mi_cross_fwd(const mi_cross_net* net, const void* x0, int64_t ld, int64_t B, void* workspace,
+                 size_t workspace_bytes, const void** x_last, void* stream);
+
+/* Backward + Adam step of every W_l, b_l.  The caller has put dL/dx_L (bf16) into workspace part DX[L] -
+ * and, with du_last_ready != 0, dL/dx_L * x0 into DU[L & 1] (an MI_EPI_CROSS_BWD epilogue with out1 stores
+ * both at once); otherwise the product is formed here.  Data gradients use the weights the forward saw.
+ * dx0 [B][ld_dx0] fp32 = dL/dx0, the gradient of the embedding rows and dense features.  lr_t / lr_dev as in
+ * mi_slab_adam. */
+int mi_cross_bwd(const mi_cross_net* net, const void* x0, int64_t ld, int64_t B, void* workspace,
+                 size_t workspace_bytes, int du_last_ready, float lr_t, const float* lr_dev, float beta1,
+                 float beta2, float eps, float* dx0, int64_t ld_dx0, void* stream);
+
+/* K-slices mi_cross_bwd / mi_din_lau_bwd use for a weight-gradient contraction [n_out][k_in] over m rows
+ * (mi_gemm_bf16 with MI_EPI_SLAB): for callers that size their own slabs the same way. */
+int mi_gemm_wgrad_splits(int64_t n_out, int64_t k_in, int64_t m);
+
+/* DIN local activation unit (see above): dim = 64; h1, h2 the PADDED hidden widths (multiples of 64), L the
+ * history length.  w3 holds w3[h2] followed by b3 (h2 + 4 floats).  factored != 0: the first layer in its
+ * factored form (h1 <= 128), whose derived tensors W1f [h1][2*dim] bf16, W1fT, Wq [h1][dim] fp32, WqT the
+ * backward call keeps current (mi_din_w1_step); W1 then needs only w, m, v.  Otherwise W1 carries its bf16
+ * copies like W2. */
+typedef struct mi_din_lau {
+  int dim, h1, h2, L, factored;
+  mi_adam_param W1, b1, W2, b2, w3;
+  void* W1f;
+  void* W1fT;
+  float* Wq;
+  float* WqT;
+} mi_din_lau;
+
+#define MI_DIN_PART_A 0       /* [B*L][a_cols] bf16 rows of the unit's input (a_cols = 2*dim factored, else 4*dim) */
+#define MI_DIN_PART_DA 1
+#define MI_DIN_PART_H1 2
+#define MI_DIN_PART_DZ1 3
+#define MI_DIN_PART_H2 4
+#define MI_DIN_PART_DH2 5
+#define MI_DIN_PART_WEIGHTS 6 /* a[B*L] fp32: the activation weights */
+size_t mi_din_lau_workspace_bytes(int64_t B, const mi_din_lau* net);
+int mi_din_lau_workspace_part(int64_t B, const mi_din_lau* net, int what, size_t* offset, size_t* bytes);
+
+/* Forward: gather + build, the unit's three layers over all B*L rows, weighted pooling.
+ * feat [B][ld_feat] fp32 = [pooled | q] (2*dim columns); ids_all [B][L+1] int32 as mi_din_lau_build writes
+ * it (the index list of the sparse backward).  B*L a multiple of 64. */
+int mi_din_lau_fwd(const mi_din_lau* net, const float* E, int64_t rows, const void* hist, const void* qid,
+                   int idx_bits, const int32_t* len, int64_t B, void* workspace, size_t workspace_bytes,
+                   float* feat, int64_t ld_feat, int32_t* ids_all, int32_t* err, void* stream);
+
+/* Backward + Adam step of the unit's parameters from dfeat [B][ld_dfeat] = dL/d[pooled | q]; the workspace
+ * and feat / ids_all as the forward of the same batch left them.  dE [B*(L+1)][dim] fp32: gradient of the
+ * gathered rows, laid out like ids_all (input of the sparse update). */
+int mi_din_lau_bwd(const mi_din_lau* net, int64_t B, void* workspace, size_t workspace_bytes,
+                   const float* feat, int64_t ld_feat, const float* dfeat, int64_t ld_dfeat,
+                   const int32_t* ids_all, float lr_t, const float* lr_dev, float beta1, float beta2,
+                   float eps, float* dE, void* stream);
+
 /* BCE-with-logits on fp32 logits: loss rows and g = (sigmoid(z) - y) * gscale (either may be NULL). */
 int mi_bce_logits(const float* logits, const float* labels, int64_t B, float gscale,
                   float* loss_rows, float* g, void* stream);

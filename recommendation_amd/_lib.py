@@ -48,6 +48,28 @@ class FmTable(Structure):
                 ('off_vs1', c_int), ('off_ws0', c_int), ('off_ws1', c_int)]
 
 
+class AdamParam(Structure):
+    """mi_adam_param"""
+    _fields_ = [('w', c_void_p), ('m', c_void_p), ('v', c_void_p), ('w_bf16', c_void_p), ('w_bf16_t', c_void_p),
+                ('grad_out', c_void_p)]
+
+
+CROSS_MAX_LAYERS = 8
+
+
+class CrossNet(Structure):
+    """mi_cross_net"""
+    _fields_ = [('n_layers', c_int), ('width', c_int), ('W', AdamParam * CROSS_MAX_LAYERS),
+                ('b', AdamParam * CROSS_MAX_LAYERS)]
+
+
+class DinLau(Structure):
+    """mi_din_lau"""
+    _fields_ = [('dim', c_int), ('h1', c_int), ('h2', c_int), ('L', c_int), ('factored', c_int), ('W1', AdamParam),
+                ('b1', AdamParam), ('W2', AdamParam), ('b2', AdamParam), ('w3', AdamParam), ('W1f', c_void_p),
+                ('W1fT', c_void_p), ('Wq', c_void_p), ('WqT', c_void_p)]
+
+
 class GemmEpilogue(Structure):
     """struct mi_gemm_epilogue"""
     _fields_ = [('mode', c_int), ('flags', c_int), ('out', c_void_p), ('ld_out', c_int64), ('bias', c_void_p),
@@ -116,6 +138,18 @@ _SIGNATURES = {
                                c_float, P, P, P, P, P, P]),
     'mi_din_lau_scatter': (c_int, [P, P, P, P, c_int64, P, c_int64, P, c_int64, c_int, c_int, P, P]),
     'mi_bce_logits': (c_int, [P, P, c_int64, c_float, P, P, P]),
+    'mi_mul_bf16': (c_int, [P, c_int64, P, c_int64, c_int64, c_int, P, c_int64, P]),
+    'mi_gemm_wgrad_splits': (c_int, [c_int64, c_int64, c_int64]),
+    'mi_cross_workspace_bytes': (c_size_t, [c_int64, c_int, c_int]),
+    'mi_cross_workspace_part': (c_int, [c_int64, c_int, c_int, c_int, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
+    'mi_cross_fwd': (c_int, [POINTER(CrossNet), P, c_int64, c_int64, P, c_size_t, POINTER(c_void_p), P]),
+    'mi_cross_bwd': (c_int, [POINTER(CrossNet), P, c_int64, c_int64, P, c_size_t, c_int, c_float, P, c_float, c_float,
+                             c_float, P, c_int64, P]),
+    'mi_din_lau_workspace_bytes': (c_size_t, [c_int64, POINTER(DinLau)]),
+    'mi_din_lau_workspace_part': (c_int, [c_int64, POINTER(DinLau), c_int, POINTER(c_size_t), POINTER(c_size_t)]),
+    'mi_din_lau_fwd': (c_int, [POINTER(DinLau), P, c_int64, P, P, c_int, P, c_int64, P, c_size_t, P, c_int64, P, P, P]),
+    'mi_din_lau_bwd': (c_int, [POINTER(DinLau), c_int64, P, c_size_t, P, c_int64, P, c_int64, P, c_float, P, c_float,
+                               c_float, c_float, P, P]),
     'mi_fm_fwd_sort_max_batch': (c_int, []),
     'mi_fm_lds_sort_single_max': (c_int, []),
     'mi_fm_fwd_sort': (c_int, [POINTER(FmTable), P, c_int, P, c_int, c_int64, P, c_int, P, P, P, c_float, P, P, P, P,

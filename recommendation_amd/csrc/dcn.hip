@@ -334,6 +334,28 @@ struct CrossPtrs {
   const unsigned short* u[8];
 };
 
+// out = a * b elementwise over [M][N] bf16 (8 values per thread)
+__global__ __launch_bounds__(256) void mul_bf16_kernel(const uint16_t* __restrict__ a, int64_t ld_a,
+                                                      const uint16_t* __restrict__ b, int64_t ld_b, int64_t M, int N,
+                                                      uint16_t* __restrict__ out, int64_t ld_out) {
+  const int per_row = N / 8;
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * per_row) return;
+  const int64_t m = i / per_row;
+  const int n = (int) (i - m * per_row) * 8;
+  const uint4 va = *reinterpret_cast<const uint4*>(a + m * ld_a + n), vb = *reinterpret_cast<const uint4*>(b + m * ld_b + n);
+  const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+  uint32_t wo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float lo = __uint_as_float(wa[j] << 16) * __uint_as_float(wb[j] << 16);
+    const float hi = __uint_as_float(wa[j] & 0xFFFF0000u) * __uint_as_float(wb[j] & 0xFFFF0000u);
+    wo[j] = (uint32_t) mi_f2bf(lo) | ((uint32_t) mi_f2bf(hi) << 16);
+  }
+  *reinterpret_cast<uint4*>(out + m * ld_out + n) = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+}
+
+
 // out = dx[0] + sum_l dx[l+1] * u[l], thread per 4 columns, l ascending
 __global__ __launch_bounds__(256) void cross_input_grad_kernel(CrossPtrs p, int L, int64_t M, int N, int64_t ld,
                                                               float* __restrict__ out, int64_t ld_out) {
@@ -450,6 +472,18 @@ extern "C" int mi_transpose_bf16(const void* src, int64_t ld_src, int R, int C, 
   MI_REQUIRE(src && dst && R >= 1 && C >= 1 && ld_src >= C && ld_dst >= R, "mi_transpose_bf16: bad arguments");
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned) mi_cdiv(C, 64), (unsigned) mi_cdiv(R, 64)), dim3(256), 0,
                      (hipStream_t) stream, (const unsigned short*) src, ld_src, R, C, (unsigned short*) dst, ld_dst);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_mul_bf16(const void* a, int64_t ld_a, const void* b, int64_t ld_b, int64_t M, int N, void* out,
+                           int64_t ld_out, void* stream) {
+  MI_REQUIRE(a && b && out && M >= 0 && N >= 8 && N % 8 == 0 && ld_a >= N && ld_b >= N && ld_out >= N && ld_a % 8 == 0 &&
+                 ld_b % 8 == 0 && ld_out % 8 == 0 && (((uintptr_t) a | (uintptr_t) b | (uintptr_t) out) & 15) == 0,
+             "mi_mul_bf16: N and the leading dimensions must be multiples of 8, pointers 16-byte aligned");
+  if (M == 0) return MI_OK;
+  hipLaunchKernelGGL(mul_bf16_kernel, dim3((unsigned) mi_cdiv(M * (N / 8), 256)), dim3(256), 0, (hipStream_t) stream,
+                     (const uint16_t*) a, ld_a, (const uint16_t*) b, ld_b, M, N, (uint16_t*) out, ld_out);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

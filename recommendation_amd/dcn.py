@@ -125,12 +125,7 @@ class DCNv2(object):
     def _splits(self, n_out, k_in, B):
         """K-slices for a dW contraction [n_out, k_in] over the batch: enough workgroups to fill the
         chip, each slice a whole number of 64-sample tiles."""
-        tiles = -(-n_out // 128) * -(-k_in // 128)
-        t64 = B // 64
-        s = max(1, min(512 // max(tiles, 1), t64))
-        while s > 1 and -(-t64 // -(-t64 // s)) != s:
-            s -= 1
-        return s
+        return ops.gemm_wgrad_splits(n_out, k_in, B)
 
     def _buffers(self, B, ids):
         if self._B == (B, ids.dtype):
@@ -140,12 +135,20 @@ class DCNv2(object):
         dev, dp = self.device, self.dp
         bf = dict(dtype=torch.bfloat16, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
-        self.x = [torch.zeros((B, dp), **bf) for _ in range(self.n_cross + 1)]
-        self.u = [torch.empty((B, dp), **bf) for _ in range(self.n_cross)]
+        # the cross network runs behind mi_cross_fwd / mi_cross_bwd; its activations and gradients live in that
+        # call pair's workspace and are used here as views (the MLP reads x_L and writes dx_L / du_{L-1} in place)
+        L = self.n_cross
+        self.cross = ops.CrossNetwork(self.Wc, self.bc, dp, B, dev, self.keep_grads) if L else None
+        self.x = [torch.zeros((B, dp), **bf)] + [self.cross.part(ops.MI_CROSS_PART_X, l) for l in range(1, L + 1)]
+        self.u = [self.cross.part(ops.MI_CROSS_PART_U, l) for l in range(L)]
         self.h = [torch.empty((B, w), **bf) for w in self.mlp]
         self.dz = [torch.empty((B, w), **bf) for w in self.mlp]
-        self.dx = [torch.empty((B, dp), **bf) for _ in range(self.n_cross + 1)]     # dx[l] = dL/dx_l
-        self.du = [torch.empty((B, dp), **bf) for _ in range(2)]
+        if L:
+            self.dx = [self.cross.part(ops.MI_CROSS_PART_DX, l) for l in range(L + 1)]     # dx[l] = dL/dx_l
+            self.du = [self.cross.part(ops.MI_CROSS_PART_DU, i) for i in range(2)]
+        else:
+            self.dx = [torch.empty((B, dp), **bf)]
+            self.du = []
         self.dx0 = torch.empty((B, dp), **f32)
         self.logit, self.loss_rows, self.g = (torch.empty((B,), **f32) for _ in range(3))
         self.loss = torch.empty((1,), **f32)
@@ -166,9 +169,8 @@ class DCNv2(object):
         x0 = self.x[0]
         ops.embag_fwd(self.V, self.toffs, self.T, ids, bag_len=1, out=x0, out_ld=self.dp, err=self.err)
         ops.pack_dense_bf16(dense if self.n_dense else None, x0, self.T * self.dim, self.dp)
-        for l in range(self.n_cross):
-            ops.gemm_bf16(self.x[l], self.Wc[l].h, ops.MI_EPI_CROSS_FWD, out=self.x[l + 1], out1=self.u[l],
-                          bias=self.bc[l].w, in0=x0, in1=self.x[l])
+        if self.n_cross:
+            self.cross.forward(x0)          # x_{l+1} = x0 * (x_l W_l^T + b_l) + x_l, one launch per layer
         a = self.x[-1]
         for i in range(len(self.mlp)):
             ops.gemm_bf16(a, self.Wm[i].h, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=self.h[i],
@@ -229,18 +231,12 @@ class DCNv2(object):
                     ops.gemm_bf16(dz, self.Wm[0].hT, ops.MI_EPI_CROSS_BWD, out=self.dx[0])
             self._weight_step(self.Wm[i], dz, inp)
             self._bias_step(self.bm[i], dz)
-        # cross layers, last first: dx_l = du_l W_l + dx_{l+1}, du_{l-1} = dx_l * x0
-        for l in reversed(range(self.n_cross)):
-            du = self.du[(l + 1) & 1]
-            if l > 0:
-                ops.gemm_bf16(du, self.Wc[l].hT, ops.MI_EPI_CROSS_BWD, out=self.dx[l], in1=self.dx[l + 1],
-                              out1=self.du[l & 1], in0=x0)
-            else:
-                ops.gemm_bf16(du, self.Wc[0].hT, ops.MI_EPI_CROSS_BWD, out=self.dx[0], in1=self.dx[1])
-            self._weight_step(self.Wc[l], du, self.x[l])
-            self._bias_step(self.bc[l], du)
-        # d x0 = dx_0 + sum_l dx_{l+1} * u_l, one pass over the stored tensors
-        ops.cross_input_grad(self.dx, self.u, self.dx0)
+        # cross layers, last first: dx_l = du_l W_l + dx_{l+1}, du_{l-1} = dx_l * x0, every layer's weight and bias
+        # step, and d x0 = dx_0 + sum_l dx_{l+1} * u_l in one pass over the stored tensors
+        if self.n_cross:
+            self.cross.backward(x0, self.dx0, self.beta1, self.beta2, self.eps, lr_dev=self.sched, du_last_ready=True)
+        else:
+            ops.cross_input_grad(self.dx, self.u, self.dx0)
         # embeddings: sort by row, sum each row's gradients in a fixed order, row-wise Adagrad
         self.plan.prepare(ids)
         ops.bwd_apply_adagrad_rowwise(self.plan, self.dx0, self.V, self.V_acc, self.emb_lr, self.emb_eps,

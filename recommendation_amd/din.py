@@ -83,10 +83,15 @@ class DIN(object):
         (after initialisation and load_state; a training step refreshes them in its weight-step kernel)."""
         D = self.dim
         Wa, Wb, Wc, Wd = (self.W1.w[:, i * D:(i + 1) * D] for i in range(4))
-        self.W1f = torch.cat([Wb - Wc, Wd], dim=1).to(torch.bfloat16).contiguous()
-        self.W1fT = self.W1f.t().contiguous()
-        self.Wq = (Wa + Wc).contiguous()
-        self.WqT = self.Wq.t().contiguous()
+        W1f = torch.cat([Wb - Wc, Wd], dim=1).to(torch.bfloat16).contiguous()
+        Wq = (Wa + Wc).contiguous()
+        if getattr(self, 'W1f', None) is None:
+            self.W1f, self.W1fT, self.Wq, self.WqT = W1f, W1f.t().contiguous(), Wq, Wq.t().contiguous()
+        else:       # in place: the unit's parameter block (ops.DinUnit) holds these tensors' addresses
+            self.W1f.copy_(W1f)
+            self.W1fT.copy_(W1f.t())
+            self.Wq.copy_(Wq)
+            self.WqT.copy_(Wq.t())
 
     def dense_params(self):
         return {'lau/W1': self.W1, 'lau/b1': self.b1, 'lau/W2': self.W2, 'lau/b2': self.b2, 'lau/w3b3': self.w3,
@@ -114,12 +119,7 @@ class DIN(object):
 
     # -- buffers ------------------------------------------------------------------------------
     def _splits(self, n_out, k_in, M):
-        tiles = -(-n_out // 128) * -(-k_in // 128)
-        t64 = M // 64
-        s = max(1, min(512 // max(tiles, 1), t64))
-        while s > 1 and -(-t64 // -(-t64 // s)) != s:
-            s -= 1
-        return s
+        return ops.gemm_wgrad_splits(n_out, k_in, M)
 
     def _buffers(self, B, hist):
         if self._B == (B, hist.dtype):
@@ -131,29 +131,19 @@ class DIN(object):
         dev = self.device
         bf = dict(dtype=torch.bfloat16, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
-        ac = (2 if self.factored else 4) * D
-        self.A = torch.empty((M, ac), **bf)
-        self.dA = torch.empty((M, ac), **bf)
-        if self.factored:
-            self.rowbias = torch.empty((B, self.h1p), **f32)
-            self.S = torch.empty((B, self.h1p), **f32)            # per-sample sums of dZ1
-            self.dq = torch.empty((B, D), **f32)
-            self.qpart = torch.empty((ops.din_qterm_part_floats(B, self.h1p, D),), **f32)
-            self.gWf = torch.empty((self.h1p, 2 * D), **f32)
-            self.gq = torch.empty((D * self.h1p + self.h1p,), **f32)   # q^T S (transposed d Wa), then d b1
-        self.H1, self.dZ1 = torch.empty((M, self.h1p), **bf), torch.empty((M, self.h1p), **bf)
-        self.H2, self.dH2 = torch.empty((M, self.h2p), **bf), torch.empty((M, self.h2p), **bf)
-        self.a, self.da = torch.empty((M,), **f32), torch.empty((M,), **f32)
+        # the unit runs behind mi_din_lau_fwd / mi_din_lau_bwd; what it keeps between the two lives in that call
+        # pair's workspace (the largest tensors are visible here as views)
+        self.unit = ops.DinUnit(self, B, dev)
+        self.A = self.unit.part(ops.MI_DIN_PART_A)
+        self.dA = self.unit.part(ops.MI_DIN_PART_DA)
+        self.H1, self.dZ1 = self.unit.part(ops.MI_DIN_PART_H1), self.unit.part(ops.MI_DIN_PART_DZ1)
+        self.H2, self.dH2 = self.unit.part(ops.MI_DIN_PART_H2), self.unit.part(ops.MI_DIN_PART_DH2)
+        self.a = self.unit.part(ops.MI_DIN_PART_WEIGHTS)
         self.ids_all = torch.empty((B, L + 1), dtype=torch.int32, device=dev)
         self.dE = torch.empty((B * (L + 1), D), **f32)
         self.feat = torch.empty((B, 2 * D), **f32)            # [pooled | q]
         self.logit, self.loss_rows, self.g = (torch.empty((B,), **f32) for _ in range(3))
         self.loss = torch.empty((1,), **f32)
-        self.split = {(self.h1p, ac): self._splits(self.h1p, ac, M),
-                      (self.h2p, self.h1p): self._splits(self.h2p, self.h1p, M)}
-        self.vec_slices = max(1, min(1024, M // 64))
-        n_slab = max(max(s * k[0] * k[1] for k, s in self.split.items()), self.vec_slices * (self.h1p + 4))
-        self.slab = torch.empty((n_slab,), **f32)
         self.plan = ops.SortedPlan(self.toffs, 1, self.rows, self.ids_all.view(-1), bag_len=1, runs=False)
         self._B = (B, hist.dtype)
 
@@ -166,41 +156,14 @@ class DIN(object):
             raise ops.MiError("DIN: history width %d differs from max_len %d" % (L, self.L))
         self._buffers(B, hist)
         D = self.dim
-        ops.din_lau_build(self.E, hist, qid, lengths, self.A, self.ids_all, q_out=self.feat[:, D:], err=self.err)
-        if self.factored:
-            # the q term of the first layer, once per sample (fp32), enters as a bias row per L positions
-            ops.din_qterm_fwd(self.feat[:, D:], self.Wq, self.b1.w, self.rowbias)
-            ops.gemm_bf16(self.A, self.W1f, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=self.H1, bias=self.rowbias,
-                          bias_rows=L)
-        else:
-            ops.gemm_bf16(self.A, self.W1.h, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=self.H1, bias=self.b1.w)
-        ops.gemm_bf16(self.H1, self.W2.h, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=self.H2, bias=self.b2.w)
-        ops.head_fwd(self.H2, self.w3.w[:self.h2p], self.w3.w[self.h2p:self.h2p + 1], None, 0.0, self.a, None, None)
-        ops.din_lau_pool(self.A, self.a, self.ids_all, D, self.feat)
+        # gather + build, the unit's three layers over all B*L rows, weighted pooling: feat = [pooled | q]
+        self.unit.forward(self.E, hist, qid, lengths, self.feat, self.ids_all, self.err)
         ops.linear_fwd(self.feat, self.head.w[:2 * D].view(2 * D, 1), self.head.w[2 * D:], out=self.logit.view(B, 1))
         if labels is not None:
             ops.bce_logits(self.logit, labels, 1.0 / B, self.loss_rows, self.g)
         return self.logit
 
     # -- one training step --------------------------------------------------------------------
-    def _apply(self, p, n_slabs, n, stride):
-        ops.slab_adam(self.slab, n_slabs, n, stride, p.w, p.m, p.v, self.beta1, self.beta2, self.eps,
-                      lr_dev=self.sched, w_bf16=p.h, grad_out=p.grad if self.keep_grads else None)
-
-    def _weight_step(self, p, dY, X):
-        n_out, k_in = p.w.shape
-        s = self.split[(n_out, k_in)]
-        ops.gemm_bf16(dY, X, ops.MI_EPI_SLAB, a_rm=True, b_rm=True, M=n_out, N=k_in, K=dY.shape[0], k_splits=s,
-                      out=self.slab[:s * n_out * k_in].view(s, n_out, k_in))
-        self._apply(p, s, n_out * k_in, n_out * k_in)
-        ops.transpose_bf16(p.h, p.hT)
-
-    def _bias_step(self, p, dY):
-        n = p.w.numel()
-        part = self.slab[:self.vec_slices * n].view(self.vec_slices, n)
-        ops.colsum_bf16(dY, self.vec_slices, part, N=n)
-        self._apply(p, self.vec_slices, n, n)
-
     def train_step(self, hist, qid, lengths, labels, check_ids=False):
         B = hist.shape[0]
         D = self.dim
@@ -213,53 +176,15 @@ class DIN(object):
         self.head.grad[2 * D:] = db
         ops.adam_tf_dense(self.head.w, self.head.m, self.head.v, self.head.grad, 0.0, self.beta1, self.beta2, self.eps,
                           lr_dev=self.sched)
-        # the unit, output side first; data gradients with the OLD weights, then the weight steps
-        ops.din_lau_pool_bwd(self.A, dfeat, self.ids_all, D, self.da)
-        part = self.slab[:self.vec_slices * (self.h2p + 4)].view(self.vec_slices, self.h2p + 4)
-        part.zero_()
-        ops.head_bwd(self.da, self.w3.w[:self.h2p], self.H2, self.dH2, self.vec_slices, part)
-        self._apply(self.w3, self.vec_slices, self.h2p + 4, self.h2p + 4)
-        ops.gemm_bf16(self.dH2, self.W2.hT, ops.MI_EPI_MASK, out=self.dZ1, in0=self.H1)
-        self._weight_step(self.W2, self.dH2, self.H1)
-        self._bias_step(self.b2, self.dH2)
-        if self.factored:
-            self._first_layer_backward_factored(B, dfeat)
-        else:
-            ops.gemm_bf16(self.dZ1, self.W1.hT, ops.MI_EPI_MASK, out=self.dA)
-            self._weight_step(self.W1, self.dZ1, self.A)
-            self._bias_step(self.b1, self.dZ1)
-            # embedding rows: per-position gradients, then sort by row + fixed-order sums + row-wise Adagrad
-            ops.din_lau_scatter(self.A, self.dA, self.a, dfeat, dfeat[:, D:], self.ids_all, D, self.dE)
+        # the unit, output side first: data gradients with the weights the forward saw, every weight step, and the
+        # per-position gradients of the gathered rows
+        self.unit.backward(self.feat, dfeat, self.ids_all, self.dE, self.beta1, self.beta2, self.eps, lr_dev=self.sched)
         self.plan.prepare(self.ids_all.view(-1))
         ops.bwd_apply_adagrad_rowwise(self.plan, self.dE, self.E, self.E_acc, self.emb_lr, self.emb_eps, grad_ld=D)
         self.steps += 1
         if check_ids:
             ops.check_error_word(self.err, "DIN ids")
         return self.loss
-
-    def _first_layer_backward_factored(self, B, dfeat):
-        """dZ1 -> gradients of [k | q*k], of q, of b1 and of the four blocks of W1, then the fused
-        weight step; data gradients are formed with the weights as the forward saw them."""
-        D, H = self.dim, self.h1p
-        q = self.feat[:, D:]
-        # S[b] = sum of dZ1 over the sample's positions: the column sums with one slice per sample
-        ops.colsum_bf16(self.dZ1, B, self.S, N=H)
-        # d q += S Wq; per 32 samples a partial of q^T S (-> d Wa) and of the column sums of S (-> d b1)
-        ops.din_qterm_bwd(q, self.S, self.Wq, dfeat[:, D:], self.dq, self.qpart)
-        stride = D * H + H
-        chunks = self.qpart.numel() // stride
-        ops.slab_adam(self.qpart, chunks, stride, stride, None, None, None, 0.0, 0.0, 0.0, grad_out=self.gq)   # chunks -> one
-        ops.slab_adam(self.gq[D * H:], 1, H, H, self.b1.w, self.b1.m, self.b1.v, self.beta1, self.beta2, self.eps,
-                      lr_dev=self.sched, grad_out=self.b1.grad if self.keep_grads else None)
-        ops.gemm_bf16(self.dZ1, self.W1fT, ops.MI_EPI_MASK, out=self.dA)
-        s = self.split[(H, 2 * D)]
-        ops.gemm_bf16(self.dZ1, self.A, ops.MI_EPI_SLAB, a_rm=True, b_rm=True, M=H, N=2 * D, K=self.dZ1.shape[0],
-                      k_splits=s, out=self.slab[:s * H * 2 * D].view(s, H, 2 * D))
-        ops.slab_adam(self.slab, s, H * 2 * D, H * 2 * D, None, None, None, 0.0, 0.0, 0.0, grad_out=self.gWf)   # slabs -> one
-        ops.din_w1_step(self.gWf, 1, H * 2 * D, self.gq, 1, stride, self.W1.w, self.W1.m, self.W1.v, self.beta1,
-                        self.beta2, self.eps, self.W1f, self.W1fT, self.Wq, self.WqT, lr_dev=self.sched,
-                        grad_out=self.W1.grad if self.keep_grads else None)
-        ops.din_lau_scatter_fact(self.A, self.dA, self.a, dfeat, self.dq, q, self.ids_all, D, self.dE)
 
     def flops_per_sample(self):
         """Multiply-adds x2 of the unit's contractions in one training step, per sample (padded widths)."""

@@ -845,3 +845,98 @@ def stage_from_host(dst, src_pinned):
     if nbytes != src_pinned.numel() * src_pinned.element_size() or not dst.is_contiguous() or not src_pinned.is_contiguous():
         raise MiError("stage_from_host: contiguous tensors of the same byte size")
     _lib.call('mi_stage_from_host', _p(dst), ctypes.c_void_p(src_pinned.data_ptr()), nbytes, _stream())
+
+
+# ---- whole-network entry points (the cross network, the DIN activation unit) ------------------------------
+MI_CROSS_PART_X, MI_CROSS_PART_U, MI_CROSS_PART_DX, MI_CROSS_PART_DU, MI_CROSS_PART_SLAB = range(5)
+(MI_DIN_PART_A, MI_DIN_PART_DA, MI_DIN_PART_H1, MI_DIN_PART_DZ1, MI_DIN_PART_H2, MI_DIN_PART_DH2,
+ MI_DIN_PART_WEIGHTS) = range(7)
+
+
+def gemm_wgrad_splits(n_out, k_in, m):
+    """K-slices of a weight-gradient contraction [n_out][k_in] over m rows (the library's own rule)."""
+    return int(_lib.load().mi_gemm_wgrad_splits(n_out, k_in, m))
+
+
+def adam_param(p, keep_grad=False):
+    """mi_adam_param of an object with tensors w, m, v (+ h, hT for matrices, + grad)."""
+    return _lib.AdamParam(w=_p(p.w), m=_p(p.m), v=_p(p.v), w_bf16=_p(getattr(p, 'h', None)),
+                          w_bf16_t=_p(getattr(p, 'hT', None)), grad_out=_p(p.grad) if keep_grad else None)
+
+
+def mul_bf16(a, b, out):
+    _lib.call('mi_mul_bf16', _p(a), a.stride(0), _p(b), b.stride(0), a.shape[0], a.shape[1], _p(out), out.stride(0),
+              _stream())
+
+
+class CrossNetwork(object):
+    """mi_cross_net + its workspace for one batch size; the workspace's tensors as views."""
+
+    def __init__(self, Ws, bs, width, B, device, keep_grads=False):
+        L = len(Ws)
+        if not 1 <= L <= _lib.CROSS_MAX_LAYERS:
+            raise MiError("CrossNetwork: 1..%d layers" % _lib.CROSS_MAX_LAYERS)
+        self.L, self.width, self.B = L, int(width), int(B)
+        self.c = _lib.CrossNet(n_layers=L, width=self.width)
+        self._keep = (Ws, bs)
+        for l in range(L):
+            self.c.W[l] = adam_param(Ws[l], keep_grads)
+            self.c.b[l] = adam_param(bs[l], keep_grads)
+        n = int(_lib.load().mi_cross_workspace_bytes(self.B, self.width, L))
+        self.ws = torch.empty((n,), dtype=torch.uint8, device=device)
+
+    def part(self, what, index=0):
+        off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.call('mi_cross_workspace_part', self.B, self.width, self.L, what, index, ctypes.byref(off), ctypes.byref(nb))
+        raw = self.ws[off.value:off.value + nb.value]
+        if what == MI_CROSS_PART_SLAB:
+            return raw.view(torch.float32)
+        return raw.view(torch.bfloat16).view(self.B, self.width)
+
+    def forward(self, x0):
+        last = ctypes.c_void_p()
+        _lib.call('mi_cross_fwd', ctypes.byref(self.c), _p(x0), x0.stride(0), self.B, _p(self.ws), self.ws.numel(),
+                  ctypes.byref(last), _stream())
+        return self.part(MI_CROSS_PART_X, self.L)
+
+    def backward(self, x0, dx0, beta1, beta2, eps, lr_t=0.0, lr_dev=None, du_last_ready=False):
+        _lib.call('mi_cross_bwd', ctypes.byref(self.c), _p(x0), x0.stride(0), self.B, _p(self.ws), self.ws.numel(),
+                  1 if du_last_ready else 0, lr_t, _p(lr_dev), beta1, beta2, eps, _p(dx0), dx0.stride(0), _stream())
+
+
+class DinUnit(object):
+    """mi_din_lau + its workspace for one batch size."""
+
+    def __init__(self, model, B, device):
+        m = model
+        self.B = int(B)
+        self.c = _lib.DinLau(dim=m.dim, h1=m.h1p, h2=m.h2p, L=m.L, factored=1 if m.factored else 0,
+                             W1=adam_param(m.W1, m.keep_grads), b1=adam_param(m.b1, m.keep_grads),
+                             W2=adam_param(m.W2, m.keep_grads), b2=adam_param(m.b2, m.keep_grads),
+                             w3=adam_param(m.w3, m.keep_grads),
+                             W1f=_p(m.W1f) if m.factored else None, W1fT=_p(m.W1fT) if m.factored else None,
+                             Wq=_p(m.Wq) if m.factored else None, WqT=_p(m.WqT) if m.factored else None)
+        self._keep = m
+        n = int(_lib.load().mi_din_lau_workspace_bytes(self.B, ctypes.byref(self.c)))
+        self.ws = torch.empty((n,), dtype=torch.uint8, device=device)
+        self.M = self.B * m.L
+
+    def part(self, what):
+        off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.call('mi_din_lau_workspace_part', self.B, ctypes.byref(self.c), what, ctypes.byref(off), ctypes.byref(nb))
+        raw = self.ws[off.value:off.value + nb.value]
+        if what == MI_DIN_PART_WEIGHTS:
+            return raw.view(torch.float32)
+        return raw.view(torch.bfloat16).view(self.M, -1)
+
+    def forward(self, E, hist, qid, lengths, feat, ids_all, err):
+        _need_cuda(E, hist, qid, lengths, feat, ids_all)
+        if qid.dtype != hist.dtype:
+            raise MiError("DinUnit: hist and qid must have the same integer type")
+        _lib.call('mi_din_lau_fwd', ctypes.byref(self.c), _p(E), E.shape[0], _p(hist.contiguous()), _p(qid.contiguous()),
+                  _idx_bits(hist), _p(lengths), self.B, _p(self.ws), self.ws.numel(), _p(feat), feat.stride(0),
+                  _p(ids_all), _p(err), _stream())
+
+    def backward(self, feat, dfeat, ids_all, dE, beta1, beta2, eps, lr_t=0.0, lr_dev=None):
+        _lib.call('mi_din_lau_bwd', ctypes.byref(self.c), self.B, _p(self.ws), self.ws.numel(), _p(feat), feat.stride(0),
+                  _p(dfeat), dfeat.stride(0), _p(ids_all), lr_t, _p(lr_dev), beta1, beta2, eps, _p(dE), _stream())
