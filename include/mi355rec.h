@@ -775,10 +775,12 @@ int mi_cross_fwd(const mi_cross_net* net, const void* x0, int64_t ld, int64_t B,
  * and, with du_last_ready != 0, dL/dx_L * x0 into DU[L & 1] (an MI_EPI_CROSS_BWD epilogue with out1 stores
  * both at once); otherwise the product is formed here.  Data gradients use the weights the forward saw.
  * dx0 [B][ld_dx0] fp32 = dL/dx0, the gradient of the embedding rows and dense features.  lr_t / lr_dev as in
- * mi_slab_adam. */
+ * mi_slab_adam.  apply_adam == 0: gradients only - every W_l, b_l gradient goes to its grad_out (required) and
+ * no parameter changes: the form a data-parallel step needs, which adds the ranks' gradients
+ * (mi_allreduce_dense) before it applies them (model_trainer.py:135-158 runs the same graph on every worker). */
 int mi_cross_bwd(const mi_cross_net* net, const void* x0, int64_t ld, int64_t B, void* workspace,
-                 size_t workspace_bytes, int du_last_ready, float lr_t, const float* lr_dev, float beta1,
-                 float beta2, float eps, float* dx0, int64_t ld_dx0, void* stream);
+                 size_t workspace_bytes, int du_last_ready, int apply_adam, float lr_t, const float* lr_dev,
+                 float beta1, float beta2, float eps, float* dx0, int64_t ld_dx0, void* stream);
 
 /* K-slices mi_cross_bwd / mi_din_lau_bwd use for a weight-gradient contraction [n_out][k_in] over m rows
  * (mi_gemm_bf16 with MI_EPI_SLAB): for callers that size their own slabs the same way. */

@@ -143,8 +143,8 @@ _SIGNATURES = {
     'mi_cross_workspace_bytes': (c_size_t, [c_int64, c_int, c_int]),
     'mi_cross_workspace_part': (c_int, [c_int64, c_int, c_int, c_int, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     'mi_cross_fwd': (c_int, [POINTER(CrossNet), P, c_int64, c_int64, P, c_size_t, POINTER(c_void_p), P]),
-    'mi_cross_bwd': (c_int, [POINTER(CrossNet), P, c_int64, c_int64, P, c_size_t, c_int, c_float, P, c_float, c_float,
-                             c_float, P, c_int64, P]),
+    'mi_cross_bwd': (c_int, [POINTER(CrossNet), P, c_int64, c_int64, P, c_size_t, c_int, c_int, c_float, P, c_float,
+                             c_float, c_float, P, c_int64, P]),
     'mi_din_lau_workspace_bytes': (c_size_t, [c_int64, POINTER(DinLau)]),
     'mi_din_lau_workspace_part': (c_int, [c_int64, POINTER(DinLau), c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     'mi_din_lau_fwd': (c_int, [POINTER(DinLau), P, c_int64, P, P, c_int, P, c_int64, P, c_size_t, P, c_int64, P, P, P]),

@@ -36,6 +36,7 @@ struct Adam {
   float lr_t;
   const float* lr_dev;
   float b1, b2, eps;
+  bool apply;  // false: gradients only (into grad_out), parameters and their bf16 copies untouched
 };
 
 #define MI_TRY(call)               \
@@ -50,6 +51,9 @@ int weight_step(const mi_adam_param& p, int64_t n_out, int64_t k_in, const void*
   const int splits = wgrad_splits(n_out, k_in, m);
   const mi_gemm_epilogue e = epi(MI_EPI_SLAB, 0, slab, k_in);
   MI_TRY(mi_gemm_bf16(1, 1, n_out, k_in, m, dY, ld_dy, X, ld_x, splits, &e, s));
+  if (!a.apply)
+    return mi_slab_adam(slab, splits, n_out * k_in, n_out * k_in, nullptr, nullptr, nullptr, 0.f, nullptr, 0.f, 0.f, 0.f,
+                        nullptr, p.grad_out, s);
   MI_TRY(mi_slab_adam(slab, splits, n_out * k_in, n_out * k_in, p.w, p.m, p.v, a.lr_t, a.lr_dev, a.b1, a.b2, a.eps,
                       p.w_bf16, p.grad_out, s));
   return mi_transpose_bf16(p.w_bf16, k_in, (int) n_out, (int) k_in, p.w_bf16_t, n_out, s);
@@ -59,6 +63,8 @@ int weight_step(const mi_adam_param& p, int64_t n_out, int64_t k_in, const void*
 int bias_step(const mi_adam_param& p, int n, const void* dY, int64_t ld_dy, int64_t m, int slices, float* slab,
               const Adam& a, void* s) {
   MI_TRY(mi_colsum_bf16(dY, ld_dy, m, n, slices, slab, n, s));
+  if (!a.apply)
+    return mi_slab_adam(slab, slices, n, n, nullptr, nullptr, nullptr, 0.f, nullptr, 0.f, 0.f, 0.f, nullptr, p.grad_out, s);
   return mi_slab_adam(slab, slices, n, n, p.w, p.m, p.v, a.lr_t, a.lr_dev, a.b1, a.b2, a.eps, nullptr, p.grad_out, s);
 }
 
@@ -236,13 +242,17 @@ extern "C" int mi_cross_fwd(const mi_cross_net* net, const void* x0, int64_t ld,
 }
 
 extern "C" int mi_cross_bwd(const mi_cross_net* net, const void* x0, int64_t ld, int64_t B, void* workspace,
-                            size_t workspace_bytes, int du_last_ready, float lr_t, const float* lr_dev, float beta1,
-                            float beta2, float eps, float* dx0, int64_t ld_dx0, void* stream) {
+                            size_t workspace_bytes, int du_last_ready, int apply_adam, float lr_t,
+                            const float* lr_dev, float beta1, float beta2, float eps, float* dx0, int64_t ld_dx0,
+                            void* stream) {
   MI_TRY(cross_check("mi_cross_bwd", net, x0, ld, B, workspace, workspace_bytes));
   MI_REQUIRE(dx0 && ld_dx0 >= net->width, "mi_cross_bwd: dx0 needs ld_dx0 >= width");
   const int L = net->n_layers, W = net->width;
+  if (!apply_adam)
+    for (int l = 0; l < L; ++l)
+      MI_REQUIRE(net->W[l].grad_out && net->b[l].grad_out, "mi_cross_bwd: gradients only, but layer %d has no grad_out", l);
   const CrossWs c = cross_carve(workspace, B, W, L);
-  const Adam a{lr_t, lr_dev, beta1, beta2, eps};
+  const Adam a{lr_t, lr_dev, beta1, beta2, eps, apply_adam != 0};
   // du_{L-1} = dx_L * x0, unless the producer of dx_L stored it already (an MI_EPI_CROSS_BWD epilogue with out1)
   if (!du_last_ready) MI_TRY(mi_mul_bf16(c.dx[L], W, x0, ld, B, W, c.du[L & 1], W, stream));
   for (int l = L - 1; l >= 0; --l) {
@@ -329,7 +339,7 @@ extern "C" int mi_din_lau_bwd(const mi_din_lau* net, int64_t B, void* workspace,
   const DinWs d = din_carve(workspace, B, net);
   const int D = net->dim, H = net->h1, H2 = net->h2, L = net->L;
   const int64_t M = B * L;
-  const Adam a{lr_t, lr_dev, beta1, beta2, eps};
+  const Adam a{lr_t, lr_dev, beta1, beta2, eps, true};
   const float* q = feat + D;
   const float* dq_above = dfeat + D;  // what the layers above send to q directly
   // the unit, output side first; data gradients with the OLD weights, then the weight steps

@@ -42,7 +42,13 @@ class _Dense(object):
 
 class DCNv2(object):
     def __init__(self, rows_per_table, dim, n_dense, device, n_cross=3, mlp=(1024, 1024, 512), lr=1e-3, emb_lr=1e-2,
-                 beta1=0.9, beta2=0.999, eps=1e-8, emb_eps=1e-8, seed=0, keep_grads=False):
+                 beta1=0.9, beta2=0.999, eps=1e-8, emb_eps=1e-8, seed=0, keep_grads=False, embeddings=True,
+                 grads_only=False, loss_ranks=1):
+        """``embeddings=False``: no table here - the step is fed the pooled rows [B][T*dim] (a sharded table's
+        output) and leaves dL/d pooled in ``self.dx0``.  ``grads_only=True``: the backward stores every dense
+        gradient in ``self.grad_arena`` and changes no parameter; ``apply_dense()`` applies them (a data-parallel
+        step adds the ranks' arenas in between).  ``loss_ranks``: ranks that share the global batch - the loss
+        gradient is scaled by 1 / (B * loss_ranks), so the SUM of the ranks' gradients is the global mean's."""
         self.device = torch.device(device)
         self.rows_per_table = [int(r) for r in rows_per_table]
         self.T, self.dim, self.n_dense = len(self.rows_per_table), int(dim), int(n_dense)
@@ -55,12 +61,16 @@ class DCNv2(object):
             if w % 64:
                 raise ValueError("MLP widths must be multiples of 64")
         self.lr, self.emb_lr, self.beta1, self.beta2, self.eps, self.emb_eps = lr, emb_lr, beta1, beta2, eps, emb_eps
-        self.keep_grads = keep_grads
+        self.embeddings, self.grads_only, self.loss_ranks = bool(embeddings), bool(grads_only), int(loss_ranks)
+        self.keep_grads = keep_grads or self.grads_only
         gen = torch.Generator(device='cpu')
         gen.manual_seed(seed)
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.V = torch.randn((self.total_rows, self.dim), generator=gen).mul_(0.05).to(self.device)
-        self.V_acc = torch.zeros((self.total_rows,), **f32)
+        if self.embeddings:
+            self.V = torch.randn((self.total_rows, self.dim), generator=gen).mul_(0.05).to(self.device)
+            self.V_acc = torch.zeros((self.total_rows,), **f32)
+        else:
+            self.V = self.V_acc = None
         d, dp = self.d, self.dp
 
         def padded(w, rows, cols):
@@ -83,12 +93,29 @@ class DCNv2(object):
         wb = torch.zeros(K + 4)
         wb[:K] = torch.randn((K,), generator=gen) / math.sqrt(K)
         self.out = _Dense(wb, self.device, False)
+        self._make_arenas()
         self.sched = torch.tensor([0.0, 1.0, 1.0, 0.0], **f32)
         self.err = ops.new_error_word(self.device)
         self.steps = 0
         self._B = None
 
     # -- parameters ---------------------------------------------------------------------------
+    def _make_arenas(self):
+        """Every dense parameter's w, m, v and gradient as views of four flat tensors: one all-reduce covers all
+        gradients, one Adam launch all parameters."""
+        ps = list(self.dense_params().values())
+        n = sum(p.w.numel() for p in ps)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.w_arena, self.m_arena, self.v_arena, self.grad_arena = (torch.zeros((n,), **f32) for _ in range(4))
+        off = 0
+        for p in ps:
+            k, shape = p.w.numel(), p.w.shape
+            for name, arena in (('w', self.w_arena), ('m', self.m_arena), ('v', self.v_arena), ('grad', self.grad_arena)):
+                view = arena[off:off + k].view(shape)
+                view.copy_(getattr(p, name))
+                setattr(p, name, view)
+            off += k
+
     def dense_params(self):
         """name -> _Dense, names as in the test oracle."""
         out = {}
@@ -102,7 +129,8 @@ class DCNv2(object):
     def load_state(self, st):
         """Copy parameters from an object with the test oracle's fields (unpadded numpy arrays)."""
         d = self.d
-        self.V.copy_(torch.from_numpy(st.V))
+        if self.embeddings:
+            self.V.copy_(torch.from_numpy(st.V))
         for l in range(self.n_cross):
             self.Wc[l].w.zero_()
             self.Wc[l].w[:d, :d] = torch.from_numpy(st.Wc[l]).to(self.device)
@@ -158,16 +186,23 @@ class DCNv2(object):
         widest = max([dp] + self.mlp + [self.mlp[-1] + 4])
         n_slab = max(max(self.split[s] * s[0] * s[1] for s in shapes), self.vec_slices * widest)
         self.slab = torch.empty((n_slab,), **f32)
-        self.plan = ops.SortedPlan(self.toffs, self.T, self.total_rows, ids, bag_len=1, runs=False)
+        self.plan = ops.SortedPlan(self.toffs, self.T, self.total_rows, ids, bag_len=1, runs=False) \
+            if self.embeddings else None
         self._B = (B, ids.dtype)
 
     # -- forward ------------------------------------------------------------------------------
-    def forward(self, ids, dense, labels=None):
-        """logits [B] (fp32); with labels also the loss rows and dL/dlogit of the mean BCE loss."""
+    def forward(self, ids, dense, labels=None, pooled=None):
+        """logits [B] (fp32); with labels also the loss rows and dL/dlogit of the mean BCE loss.  Without a table
+        of its own (``embeddings=False``) the rows come as ``pooled`` [B][T*dim] fp32."""
         B = ids.shape[0]
         self._buffers(B, ids)
         x0 = self.x[0]
-        ops.embag_fwd(self.V, self.toffs, self.T, ids, bag_len=1, out=x0, out_ld=self.dp, err=self.err)
+        if self.embeddings:
+            ops.embag_fwd(self.V, self.toffs, self.T, ids, bag_len=1, out=x0, out_ld=self.dp, err=self.err)
+        else:
+            if pooled is None or tuple(pooled.shape) != (B, self.T * self.dim):
+                raise ops.MiError("DCNv2 without embeddings: pooled must be [B][T*dim]")
+            ops.pack_dense_bf16(pooled, x0, 0, self.T * self.dim)
         ops.pack_dense_bf16(dense if self.n_dense else None, x0, self.T * self.dim, self.dp)
         if self.n_cross:
             self.cross.forward(x0)          # x_{l+1} = x0 * (x_l W_l^T + b_l) + x_l, one launch per layer
@@ -177,14 +212,26 @@ class DCNv2(object):
                           bias=self.bm[i].w)
             a = self.h[i]
         K = self.mlp[-1]
-        ops.head_fwd(a, self.out.w[:K], self.out.w[K:K + 1], labels, 1.0 / B, self.logit,
+        ops.head_fwd(a, self.out.w[:K], self.out.w[K:K + 1], labels, 1.0 / (B * self.loss_ranks), self.logit,
                      self.loss_rows if labels is not None else None, self.g if labels is not None else None)
         return self.logit
 
     # -- one training step --------------------------------------------------------------------
     def _apply(self, p, n_slabs, n, stride):
+        if self.grads_only:         # the slabs added up into the gradient, nothing else
+            ops.slab_adam(self.slab, n_slabs, n, stride, None, None, None, 0.0, 0.0, 0.0, grad_out=p.grad)
+            return
         ops.slab_adam(self.slab, n_slabs, n, stride, p.w, p.m, p.v, self.beta1, self.beta2, self.eps,
                       lr_dev=self.sched, w_bf16=p.h, grad_out=p.grad if self.keep_grads else None)
+
+    def apply_dense(self):
+        """After a ``grads_only`` backward: TensorFlow-form Adam on every dense parameter from ``grad_arena`` (one
+        launch), then the bf16 working copies of the matrices in both orientations."""
+        ops.adam_tf_dense(self.w_arena, self.m_arena, self.v_arena, self.grad_arena, 0.0, self.beta1, self.beta2, self.eps,
+                          lr_dev=self.sched)
+        for p in self.Wc + self.Wm:
+            ops.cast_bf16(p.w, p.h)
+            ops.transpose_bf16(p.h, p.hT)
 
     def _weight_step(self, p, dY, X):
         """dW = dY^T X as split-K slabs, then the fused reduction + Adam + bf16 re-cast."""
@@ -193,7 +240,8 @@ class DCNv2(object):
         ops.gemm_bf16(dY, X, ops.MI_EPI_SLAB, a_rm=True, b_rm=True, M=n_out, N=k_in, K=dY.shape[0], k_splits=s,
                       out=self.slab[:s * n_out * k_in].view(s, n_out, k_in))
         self._apply(p, s, n_out * k_in, n_out * k_in)
-        ops.transpose_bf16(p.h, p.hT)
+        if not self.grads_only:
+            ops.transpose_bf16(p.h, p.hT)
 
     def _bias_step(self, p, dY):
         n = p.w.numel()
@@ -201,10 +249,10 @@ class DCNv2(object):
         ops.colsum_bf16(dY, self.vec_slices, part, N=n)
         self._apply(p, self.vec_slices, n, n)
 
-    def train_step(self, ids, dense, labels, check_ids=False):
+    def train_step(self, ids, dense, labels, check_ids=False, pooled=None):
         """Forward, backward and every optimizer update; returns the mean loss (1-element tensor)."""
         B = ids.shape[0]
-        self.forward(ids, dense, labels)
+        self.forward(ids, dense, labels, pooled=pooled)
         ops.reduce_sum(self.loss_rows, 1.0 / B, out=self.loss)
         ops.adam_schedule_step(self.sched, self.lr, self.beta1, self.beta2)
         x0 = self.x[0]
@@ -234,13 +282,15 @@ class DCNv2(object):
         # cross layers, last first: dx_l = du_l W_l + dx_{l+1}, du_{l-1} = dx_l * x0, every layer's weight and bias
         # step, and d x0 = dx_0 + sum_l dx_{l+1} * u_l in one pass over the stored tensors
         if self.n_cross:
-            self.cross.backward(x0, self.dx0, self.beta1, self.beta2, self.eps, lr_dev=self.sched, du_last_ready=True)
+            self.cross.backward(x0, self.dx0, self.beta1, self.beta2, self.eps, lr_dev=self.sched, du_last_ready=True,
+                                apply_adam=not self.grads_only)
         else:
             ops.cross_input_grad(self.dx, self.u, self.dx0)
         # embeddings: sort by row, sum each row's gradients in a fixed order, row-wise Adagrad
-        self.plan.prepare(ids)
-        ops.bwd_apply_adagrad_rowwise(self.plan, self.dx0, self.V, self.V_acc, self.emb_lr, self.emb_eps,
-                                      grad_ld=self.dp)
+        if self.embeddings:
+            self.plan.prepare(ids)
+            ops.bwd_apply_adagrad_rowwise(self.plan, self.dx0, self.V, self.V_acc, self.emb_lr, self.emb_eps,
+                                          grad_ld=self.dp)
         self.steps += 1
         if check_ids:
             ops.check_error_word(self.err, "DCN ids")

@@ -899,9 +899,11 @@ class CrossNetwork(object):
                   ctypes.byref(last), _stream())
         return self.part(MI_CROSS_PART_X, self.L)
 
-    def backward(self, x0, dx0, beta1, beta2, eps, lr_t=0.0, lr_dev=None, du_last_ready=False):
+    def backward(self, x0, dx0, beta1, beta2, eps, lr_t=0.0, lr_dev=None, du_last_ready=False, apply_adam=True):
+        """``apply_adam=False``: gradients only, into the parameters' ``grad`` tensors (``keep_grads`` at construction)."""
         _lib.call('mi_cross_bwd', ctypes.byref(self.c), _p(x0), x0.stride(0), self.B, _p(self.ws), self.ws.numel(),
-                  1 if du_last_ready else 0, lr_t, _p(lr_dev), beta1, beta2, eps, _p(dx0), dx0.stride(0), _stream())
+                  1 if du_last_ready else 0, 1 if apply_adam else 0, lr_t, _p(lr_dev), beta1, beta2, eps, _p(dx0),
+                  dx0.stride(0), _stream())
 
 
 class DinUnit(object):

@@ -117,6 +117,10 @@ class TorchComm(object):
     def all_gather(self, out, inp):
         dist.all_gather_into_tensor(out, inp, group=self.group)
 
+    def all_reduce(self, buf):
+        """buf (fp32, in place) <- the sum of every rank's buf."""
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+
 
 class RcclComm(object):
     """The same collectives through the library's own RCCL entry points (mi_comm_*, mi_a2a_*,
