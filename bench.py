@@ -458,15 +458,29 @@ def bench_dcn(args):
     # every contraction launch of the step timed on its own, by kernel class: 'row' = gemm_bf16_kernel with both
     # operands stored reduction-contiguous (forward layers and data gradients), 'wgrad' = both reduction-major
     # (weight gradients).  The roofline line is the class that takes more of the step, ALL its launches summed.
+    # Beside each: the vendor library's product of the SAME two operands (torch.matmul -> hipBLASLt / rocBLAS), which
+    # stores one bf16 (row class) or fp32 (weight gradients) result and nothing else - no bias, activation, cross
+    # term, mask or second output, which this library's launches fuse into the same pass.
     per = []
-    for cls, name, fn, flops in m.contraction_calls():
+    for cls, name, fn, flops, (opa, opb) in m.contraction_calls():
         ms = time_stage(fn, max(2, args.stage_reps // 5))
-        per.append(dict(kernel_class=cls, name=name, ms=round(ms, 5), flops=flops, tflops=round(flops / ms / 1e9, 1)))
+        if cls == 'row':
+            out = torch.empty((opa.shape[0], opb.shape[0]), dtype=torch.bfloat16, device=dev)
+            vfn = lambda opa=opa, opb=opb, out=out: torch.matmul(opa, opb.t(), out=out)           # noqa: E731
+        else:
+            out = torch.empty((opa.shape[1], opb.shape[1]), dtype=torch.bfloat16, device=dev)
+            vfn = lambda opa=opa, opb=opb, out=out: torch.matmul(opa.t(), opb, out=out)           # noqa: E731
+        vms = time_stage(vfn, max(2, args.stage_reps // 5))
+        per.append(dict(kernel_class=cls, name=name, ms=round(ms, 5), flops=flops, tflops=round(flops / ms / 1e9, 1),
+                        vendor_ms=round(vms, 5), vendor_tflops=round(flops / vms / 1e9, 1)))
     res['contractions'] = per
     tot = {c: (sum(p['flops'] for p in per if p['kernel_class'] == c), sum(p['ms'] for p in per if p['kernel_class'] == c))
            for c in ('row', 'wgrad')}
+    vtot = {c: sum(p['vendor_ms'] for p in per if p['kernel_class'] == c) for c in ('row', 'wgrad')}
     res['contraction_classes'] = {c: dict(launches=sum(1 for p in per if p['kernel_class'] == c), ms=round(t, 4),
-                                          tflops=round(f / t / 1e9, 1)) for c, (f, t) in tot.items()}
+                                          tflops=round(f / t / 1e9, 1), vendor_ms=round(vtot[c], 4),
+                                          vendor_tflops=round(f / vtot[c] / 1e9, 1)) for c, (f, t) in tot.items()}
+    res['vendor_comparator'] = 'torch.matmul (bf16, %s) on the same operands, product only' % torch.__version__
     dom = max(tot, key=lambda c: tot[c][1])
     flops, ms = tot[dom]
     n_launch = res['contraction_classes'][dom]['launches']
@@ -620,7 +634,8 @@ def bench_embag(args):
     kern = 'embag_fwd_kernel' if dom is stages[0] else 'seg_sorted_kernel'
     res['roofline'] = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': round(dom['gbs'] / HBM_PEAK_GBS, 4),
-                       'traffic': (_pmc_traffic('r02_embag_b65536_%s_pmc.json' % opt, res['config']['workload'], kern) or
+                       'traffic': (_pmc_traffic('r03_embag_b65536_%s_pmc.json' % opt, res['config']['workload'], kern) or
+                                   _pmc_traffic('r02_embag_b65536_%s_pmc.json' % opt, res['config']['workload'], kern) or
                                    _pmc_traffic('r01_embag_b65536_%s_pmc.json' % opt, res['config']['workload'], kern)),
                        'traffic_source': 'quoted profiles/r0x_embag_b65536_%s_pmc.json (null when absent or another workload)' % opt,
                        'alg_bytes_per_launch': dom['alg_bytes'], 'ms_per_launch': dom['ms']}
@@ -813,9 +828,10 @@ def bench_din(args):
                        'achieved': round(nbytes / ms / 1e6, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                        # the committed counter passes ran the factored form (the default)
-                       'traffic': (_pmc_traffic('r02_din_b8192_pmc.json', res['config']['workload'], 'din_build_kernel')
+                       'traffic': ((_pmc_traffic('r03_din_b8192_pmc.json', res['config']['workload'], 'din_build_kernel') or
+                                    _pmc_traffic('r02_din_b8192_pmc.json', res['config']['workload'], 'din_build_kernel'))
                                    if m.factored else None),
-                       'traffic_source': 'quoted profiles/r02_din_b8192_pmc.json (null when absent or another workload)',
+                       'traffic_source': 'quoted profiles/r0x_din_b8192_pmc.json (null when absent or another workload)',
                        'alg_bytes_per_launch': nbytes, 'ms_per_launch': round(ms, 5)}
     if not args.no_cpu_baseline:
         from oracle import din as odin

@@ -298,22 +298,23 @@ class DCNv2(object):
 
     # -- the step's contractions, one by one (for per-kernel timing) ----------------------------
     def contraction_calls(self):
-        """[(class, name, fn, flops)] for every mi_gemm_bf16 launch of one training step on the buffers
+        """[(class, name, fn, flops, (A, B))] for every mi_gemm_bf16 launch of one training step on the buffers
         the last step left behind: class 'row' = both operands stored reduction-contiguous (forward layers
         and data gradients), 'wgrad' = both reduction-major (weight gradients, split-K slabs).  The calls
-        write the same tensors the step writes; weights are not touched."""
+        write the same tensors the step writes; weights are not touched.  (A, B): the two bf16 operands - class 'row'
+        computes A B^T (+ epilogue), class 'wgrad' A^T B - for timing another library's product on the same data."""
         B = self.x[0].shape[0]
         x0, L, n_mlp = self.x[0], self.n_cross, len(self.mlp)
         calls = []
         for l in range(L):
             calls.append(('row', 'cross%d fwd' % l, (lambda l=l: ops.gemm_bf16(
                 self.x[l], self.Wc[l].h, ops.MI_EPI_CROSS_FWD, out=self.x[l + 1], out1=self.u[l], bias=self.bc[l].w, in0=x0,
-                in1=self.x[l])), 2.0 * B * self.dp * self.dp))
+                in1=self.x[l])), 2.0 * B * self.dp * self.dp, (self.x[l], self.Wc[l].h)))
         a = self.x[-1]
         for i in range(n_mlp):
             calls.append(('row', 'mlp%d fwd' % i, (lambda i=i, a=a: ops.gemm_bf16(
                 a, self.Wm[i].h, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=self.h[i], bias=self.bm[i].w)),
-                2.0 * B * self.Wm[i].w.shape[0] * self.Wm[i].w.shape[1]))
+                2.0 * B * self.Wm[i].w.shape[0] * self.Wm[i].w.shape[1], (a, self.Wm[i].h)))
             a = self.h[i]
         for i in reversed(range(n_mlp)):
             dz = self.dz[i]
@@ -321,28 +322,30 @@ class DCNv2(object):
             n_out, k_in = self.Wm[i].w.shape
             if i > 0:
                 calls.append(('row', 'mlp%d dX' % i, (lambda i=i, dz=dz: ops.gemm_bf16(
-                    dz, self.Wm[i].hT, ops.MI_EPI_MASK, out=self.dz[i - 1], in0=self.h[i - 1])), 2.0 * B * n_out * k_in))
+                    dz, self.Wm[i].hT, ops.MI_EPI_MASK, out=self.dz[i - 1], in0=self.h[i - 1])), 2.0 * B * n_out * k_in,
+                    (dz, self.Wm[i].hT)))
             else:
                 calls.append(('row', 'mlp0 dX', (lambda dz=dz: ops.gemm_bf16(
                     dz, self.Wm[0].hT, ops.MI_EPI_CROSS_BWD, out=self.dx[L], out1=self.du[L & 1], in0=x0)),
-                    2.0 * B * n_out * k_in))
+                    2.0 * B * n_out * k_in, (dz, self.Wm[0].hT)))
             s = self.split[(n_out, k_in)]
             calls.append(('wgrad', 'mlp%d dW' % i, (lambda dz=dz, inp=inp, s=s, n_out=n_out, k_in=k_in: ops.gemm_bf16(
                 dz, inp, ops.MI_EPI_SLAB, a_rm=True, b_rm=True, M=n_out, N=k_in, K=dz.shape[0], k_splits=s,
-                out=self.slab[:s * n_out * k_in].view(s, n_out, k_in))), 2.0 * B * n_out * k_in))
+                out=self.slab[:s * n_out * k_in].view(s, n_out, k_in))), 2.0 * B * n_out * k_in, (dz, inp)))
         for l in reversed(range(L)):
             du = self.du[(l + 1) & 1]
             if l > 0:
                 calls.append(('row', 'cross%d dX' % l, (lambda l=l, du=du: ops.gemm_bf16(
                     du, self.Wc[l].hT, ops.MI_EPI_CROSS_BWD, out=self.dx[l], in1=self.dx[l + 1], out1=self.du[l & 1],
-                    in0=x0)), 2.0 * B * self.dp * self.dp))
+                    in0=x0)), 2.0 * B * self.dp * self.dp, (du, self.Wc[l].hT)))
             else:
                 calls.append(('row', 'cross0 dX', (lambda du=du: ops.gemm_bf16(
-                    du, self.Wc[0].hT, ops.MI_EPI_CROSS_BWD, out=self.dx[0], in1=self.dx[1])), 2.0 * B * self.dp * self.dp))
+                    du, self.Wc[0].hT, ops.MI_EPI_CROSS_BWD, out=self.dx[0], in1=self.dx[1])), 2.0 * B * self.dp * self.dp,
+                    (du, self.Wc[0].hT)))
             s = self.split[(self.dp, self.dp)]
             calls.append(('wgrad', 'cross%d dW' % l, (lambda l=l, du=du, s=s: ops.gemm_bf16(
                 du, self.x[l], ops.MI_EPI_SLAB, a_rm=True, b_rm=True, M=self.dp, N=self.dp, K=du.shape[0], k_splits=s,
-                out=self.slab[:s * self.dp * self.dp].view(s, self.dp, self.dp))), 2.0 * B * self.dp * self.dp))
+                out=self.slab[:s * self.dp * self.dp].view(s, self.dp, self.dp))), 2.0 * B * self.dp * self.dp, (du, self.x[l])))
         return calls
 
     # -- accounting ---------------------------------------------------------------------------
