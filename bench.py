@@ -74,6 +74,8 @@ def parse_args():
                     help='embag workload: total rows over the 26 tables (default: one GPU\'s eighth of 1 G rows); '
                          'sharded_embag: rows PER RANK')
     ap.add_argument('--din-items', type=int, default=8000000, help='din workload: rows of the item table')
+    ap.add_argument('--id-exchange', choices=['all_gather', 'bucketed'], default='all_gather',
+                    help='sharded_embag workload: all-gather of the ids, or an all-to-all of the ids bucketed by owner')
     ap.add_argument('--no-host-fed', action='store_true',
                     help='fm workload: skip the extra line that feeds every batch from pinned host memory')
     ap.add_argument('--workload', default='fm', choices=['fm', 'dcn', 'din', 'infer', 'embag', 'sharded_embag', 'colour'],
@@ -676,7 +678,7 @@ def bench_sharded_embag(args):
     if args.comm == 'rccl':     # the library's own RCCL entry points, enqueued on the compute stream itself
         from recommendation_amd.sharded import RcclComm
         comm = RcclComm()
-    m = ShardedEmbeddingBag(rows, D, L, dev, opt=opt, lr=0.01, seed=0, comm=comm)
+    m = ShardedEmbeddingBag(rows, D, L, dev, opt=opt, lr=0.01, seed=0, comm=comm, id_exchange=args.id_exchange)
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + rank)
     card = torch.tensor(rows, dtype=torch.float64, device=dev).view(1, T, 1)
@@ -732,18 +734,46 @@ def bench_sharded_embag(args):
                                           "the library's RCCL entry points on the compute stream"),
                           'parallelism': 'rowwise-sharded tables x%d, pooled rows exchanged' % world}}
         res['host_issue_ms_per_step'] = round(t_issue / args.steps * 1e3, 4)   # == ms_per_step when the host is the bound
-        res['collectives'] = {'all_gather_ids_bytes_received': world * n_bags * L * ib,
+        res['config']['id_exchange'] = args.id_exchange
+        res['collectives'] = {('all_gather_ids_bytes_received' if not m.bucketed else 'all_to_all_bucketed_ids_bytes_per_rank'):
+                              (world * n_bags * L * ib if not m.bucketed else world * (m.cap_ids * 4 + m.cap * 8)),
                               'all_to_all_pooled_rows_bytes_per_rank': world * m.cap * D * 4,
                               'all_to_all_gradient_rows_bytes_per_rank': world * m.cap * D * 4,
                               'rows_that_carry_data_per_exchange': n_bags if L == 1 else None}
     # per-launch stages on rank 0's buffers of the last step (no collectives inside)
     ids = batches[(it[0] - 1) % len(batches)]
-    n_own = int(m.own_cnt.sum().item())
-    n_ent = int((m.local_ids >= 0).sum().item())
     plan = m.be._plan
-    U = int(torch.unique(plan.sorted_rows[:plan.n_entries]).numel()) - (1 if n_ent < plan.n_entries else 0)
-    stages = []
-    for name, fn, nb in (
+    opt_code = ops.MI_OPT_SGD if opt == 'sgd' else ops.MI_OPT_ADAGRAD_ROWWISE
+    if m.bucketed:
+        n_own = world * m.cap
+        n_ent = int((m.recv_ids >= 0).sum().item())
+        U = int(torch.unique(plan.sorted_rows[:plan.n_entries]).numel()) - (1 if n_ent < plan.n_entries else 0)
+
+        def upd0():
+            g = m.grad_in.view(-1, D)
+            if opt == 'sgd':
+                ops.bwd_apply_sgd(plan, g, m.be.W, 0.0)
+            else:
+                ops.bwd_apply_adagrad_rowwise(plan, g, m.be.W, m.be.state, 0.0, 1e-8)
+        stage_list = (
+            ('requester slots + ids bucketed by owner (4 launches, 1 fill)', lambda: m.phase_bucket(ids.reshape(B, T, L)),
+             2 * n_bags * L * ib + world * n_bags * 5 + world * (m.cap_ids * 4 + m.cap * 8)),
+            ('owner gather + partial pooling (mi_embag_fwd over the received CSR bags)',
+             lambda: m.be.gather_csr(m.recv_ids, m.recv_off, m.rows_out),
+             world * (m.cap_ids * 4 + m.cap * 8) + n_ent * D * 4 + n_own * D * 4),
+            ('requester combine', lambda: m.be.combine(m.rows_in, m.req_row_of_bag, m.n_bags, m.pooled),
+             world * n_bags * 4 + n_bags * D * 4 * 2),
+            ('requester gradient pack', lambda: m.be.pack(grad, m.req_bag_of_row, m.req_cnt, m.cap, m.grad_out),
+             n_bags * (4 + D * 4 * 2)),
+            ('owner sort by row (CSR)', lambda: plan.prepare(m.recv_ids), plan.n_entries * 12),
+            ('owner sparse backward + fused %s' % opt, upd0,
+             n_ent * (8 + 4 + D * 4) + U * (D + (1 if opt != 'sgd' else 0)) * 4 * 2))
+        hbm_idx = (1, 5)
+    else:
+        n_own = int(m.own_cnt.sum().item())
+        n_ent = int((m.local_ids >= 0).sum().item())
+        U = int(torch.unique(plan.sorted_rows[:plan.n_entries]).numel()) - (1 if n_ent < plan.n_entries else 0)
+        stage_list = (
             ('owner slots (2 launches: ownership flags, local ids, block rows)',
              lambda: m.be.owner_slots(m.ids_all, m.n_bags, m.cap, m.local_ids, m.own_row_of_bag, m.own_bag_of_row, m.own_cnt, m.ws),
              world * n_bags * L * (ib + 4) + world * n_bags * 5),
@@ -758,15 +788,18 @@ def bench_sharded_embag(args):
              n_bags * (4 + D * 4 * 2)),
             ('owner sort by row', lambda: plan.prepare(m.local_ids), plan.n_entries * 12),
             ('owner sparse backward + fused %s' % opt,
-             lambda: ops.bwd_apply_rows(plan, m.grad_in, m.own_row_of_bag, m.be.W, ops.MI_OPT_SGD if opt == 'sgd' else ops.MI_OPT_ADAGRAD_ROWWISE, 0.0, state=m.be.state),
-             n_ent * (8 + 4 + D * 4) + U * (D + (1 if opt != 'sgd' else 0)) * 4 * 2)):
+             lambda: ops.bwd_apply_rows(plan, m.grad_in, m.own_row_of_bag, m.be.W, opt_code, 0.0, state=m.be.state),
+             n_ent * (8 + 4 + D * 4) + U * (D + (1 if opt != 'sgd' else 0)) * 4 * 2))
+        hbm_idx = (1, 6)
+    stages = []
+    for name, fn, nb in stage_list:
         ms = time_stage(fn, args.stage_reps)
         stages.append(dict(name=name, ms=round(ms, 5), alg_bytes=int(nb), gbs=round(nb / ms / 1e6, 1)))
     if rank == 0:
         res['stages'] = stages
         res['entries_at_this_owner'] = n_ent
         res['unique_rows_per_step'] = U
-        hbm = [stages[1], stages[6]]
+        hbm = [stages[i] for i in hbm_idx]
         dom = max(hbm, key=lambda s: s['ms'])
         res['embedding_hbm_gbs'] = round(sum(s['alg_bytes'] for s in hbm) / sum(s['ms'] for s in hbm) / 1e6, 1)
         res['roofline'] = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': dom['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -539,6 +539,23 @@ int mi_shard_bag_slots(const int64_t* table_offsets, int T, const void* ids, int
                        int32_t* local_ids, int32_t* row_of_bag, int32_t* bag_of_row, int32_t* cnt,
                        void* workspace, size_t workspace_bytes, int32_t* err, void* stream);
 
+/* Bucketed id exchange (instead of the all-gather of ids): block p of this rank's send buffers is the CSR form of
+ * "my bags that rank p contributes to" - send_ids[p][cap_ids] int32, rank p's ids already as ITS local rows
+ * (global row / N) packed in bag order, -1 behind the last; send_off[p][cap] int64, the first id of each slot's
+ * bag, absolute in the OWNER's receive buffer (this rank's block starts there at rank*cap_ids).  After the two
+ * all-to-alls the owner holds ids[N*cap_ids] and off[N*cap] (+ one closing entry N*cap_ids it sets once) and runs
+ * the ordinary CSR embedding bag over its local rows: mi_embag_fwd(T = 1, offsets = off, n_bags = N*cap) writes
+ * the send blocks of the row exchange, mi_embag_bwd_prepare + mi_embag_bwd_apply_* on the same ids / offsets with
+ * the received gradient rows update its rows.  row_of_bag / cnt: the requester view of mi_shard_bag_slots for the
+ * same ids.  Bytes on the wire: 4 per id + 8 per (bag, owner) against 8*N per id.  More than cap_ids ids for one
+ * owner: MI_IDERR_CAPACITY in *err.  Two launches + one fill. */
+size_t mi_shard_bag_bucket_workspace_bytes(int64_t n_bags, int n_ranks);
+int mi_shard_bag_bucket(const int64_t* table_offsets, int T, const void* ids, int idx_bits, int bag_len,
+                        int64_t n_bags, int rank, int n_ranks, int64_t cap, int64_t cap_ids,
+                        const int32_t* row_of_bag, const int32_t* cnt, int32_t* send_ids, int64_t* send_off,
+                        void* workspace, size_t workspace_bytes, int32_t* err, void* stream);
+
+
 /* Owner: out_rows[p*cap + slot][dim] = sum over the local ids >= 0 of bag bag_of_row[..] of part p of
  * weights[local_table_offsets[t] + local id].  weights is this rank's share [local rows][dim];
  * local_table_offsets[T+1] (int64, device): local rows that belong to tables before t, i.e.

@@ -168,6 +168,9 @@ _SIGNATURES = {
     'mi_shard_owner_bwd_dense': (c_int, [POINTER(FmTable), c_int64, P, P, P, c_int64, P, c_int, c_int, c_int64, c_int64, c_int, c_float,
                                          P, c_float, c_float, c_float, c_int, P, P, P, c_float, P, P, P, P]),
     'mi_shard_bag_slots_workspace_bytes': (c_size_t, [c_int64, c_int]),
+    'mi_shard_bag_bucket_workspace_bytes': (c_size_t, [c_int64, c_int]),
+    'mi_shard_bag_bucket': (c_int, [P, c_int, P, c_int, c_int, c_int64, c_int, c_int, c_int64, c_int64, P, P, P, P, P,
+                                    c_size_t, P, P]),
     'mi_shard_bag_slots': (c_int, [P, c_int, P, c_int, c_int, c_int64, c_int, c_int, c_int, c_int64, P, P, P, P, P,
                                    c_size_t, P, P]),
     'mi_shard_bag_gather': (c_int, [P, P, c_int, c_int, P, c_int, c_int64, c_int, c_int64, P, P, P, P]),

@@ -239,6 +239,110 @@ int row_geometry(const char* who, int dim, int* lanes, int* groups) {
   return MI_OK;
 }
 
+
+// ---- bucketed id exchange -----------------------------------------------------------------------------
+// Instead of every rank seeing every rank's ids (all-gather: N times the ids at 8 bytes each), a requester sends
+// each owner ONLY the ids that owner holds, already as the owner's local rows (global row / N, int32), packed in
+// bag order behind per-slot offsets: block p = the CSR form of "my bags that rank p contributes to".  The owner's
+// side is then the ordinary CSR embedding bag over its local rows (mi_embag_fwd / mi_embag_bwd_prepare with
+// offsets), N*cap bags in all.
+//
+// Pass 1: ids of each 256-bag chunk that rank p holds, counted over the bags that have a slot in p's block.
+template <typename IDX>
+__global__ __launch_bounds__(SB_BLOCK) void bag_idcount_kernel(const int64_t* __restrict__ toffs, int T,
+                                                              const void* __restrict__ ids, int L, int n_bags, int N,
+                                                              const int32_t* __restrict__ row_of_bag,
+                                                              int32_t* __restrict__ chunk_ids, int n_chunks) {
+  __shared__ int wcnt[SB_BLOCK / 64];
+  const int p = blockIdx.y;
+  const int bag = blockIdx.x * SB_BLOCK + threadIdx.x;
+  int c = 0;
+  if (bag < n_bags && row_of_bag[(int64_t) p * n_bags + bag] >= 0) {
+    const int t = bag % T;
+    const int64_t base = toffs[t], rows = toffs[t + 1] - base;
+    for (int l = 0; l < L; ++l) {
+      const int64_t id = mi_ld_id<IDX>(ids, (int64_t) bag * L + l);
+      c += (id >= 0 && id < rows && (int) ((base + id) % N) == p) ? 1 : 0;
+    }
+  }
+  int w = c;
+  for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_ids[(int64_t) p * n_chunks + blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+// Pass 2: every bag with a slot writes its ids of rank p, as local rows, at its place in block p (chunks before it +
+// bags before it in the chunk) and its slot's offset - absolute in the owner's receive buffer, where this rank's
+// block starts at rank * cap_ids.  Slots beyond the block's last bag get the end of the used part, so that the
+// block's unused tail (left at -1 by the caller's fill: padding ids) belongs to no bag but the last, harmlessly.
+template <typename IDX>
+__global__ __launch_bounds__(SB_BLOCK) void bag_bucket_kernel(const int64_t* __restrict__ toffs, int T,
+                                                             const void* __restrict__ ids, int L, int n_bags, int N,
+                                                             int rank, int cap, int64_t cap_ids,
+                                                             const int32_t* __restrict__ row_of_bag,
+                                                             const int32_t* __restrict__ cnt,
+                                                             const int32_t* __restrict__ chunk_ids, int n_chunks,
+                                                             int32_t* __restrict__ send_ids,
+                                                             int64_t* __restrict__ send_off, int32_t* __restrict__ err) {
+  __shared__ int red[SB_BLOCK];
+  __shared__ int wsum[SB_BLOCK / 64];
+  const int p = blockIdx.y, chunk = blockIdx.x;
+  int s = 0;
+  for (int i = threadIdx.x; i < chunk; i += SB_BLOCK) s += chunk_ids[(int64_t) p * n_chunks + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = SB_BLOCK / 2; o > 0; o >>= 1) {
+    if ((int) threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const int base = red[0];
+  const int bag = chunk * SB_BLOCK + threadIdx.x;
+  const int r = bag < n_bags ? row_of_bag[(int64_t) p * n_bags + bag] : -1;
+  int c = 0;
+  int64_t tbase = 0, rows = 0;
+  if (r >= 0) {
+    const int t = bag % T;
+    tbase = toffs[t];
+    rows = toffs[t + 1] - tbase;
+    for (int l = 0; l < L; ++l) {
+      const int64_t id = mi_ld_id<IDX>(ids, (int64_t) bag * L + l);
+      c += (id >= 0 && id < rows && (int) ((tbase + id) % N) == p) ? 1 : 0;
+    }
+  }
+  // exclusive prefix of c over the chunk's 256 bags
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int before = 0;
+  for (int i = 0; i < w; ++i) before += wsum[i];
+  const int64_t pos = (int64_t) base + before + incl - c;
+  const int64_t block0 = (int64_t) rank * cap_ids;  // where this rank's block lies in the owner's receive buffer
+  if (r >= 0) {
+    send_off[(int64_t) p * cap + (r - p * cap)] = block0 + (pos < cap_ids ? pos : cap_ids);
+    if (pos + c <= cap_ids) {
+      int32_t* dst = send_ids + (int64_t) p * cap_ids + pos;
+      int k = 0;
+      for (int l = 0; l < L; ++l) {
+        const int64_t id = mi_ld_id<IDX>(ids, (int64_t) bag * L + l);
+        if (id >= 0 && id < rows && (int) ((tbase + id) % N) == p) dst[k++] = (int32_t) ((tbase + id) / N);
+      }
+    } else if (err) {
+      atomicOr(err, MI_IDERR_CAPACITY);
+    }
+  }
+  if (chunk == n_chunks - 1) {
+    const int total = base + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const int64_t end = block0 + (total < cap_ids ? total : cap_ids);
+    for (int slot = cnt[p] + (int) threadIdx.x; slot < cap; slot += SB_BLOCK) send_off[(int64_t) p * cap + slot] = end;
+  }
+}
+
 size_t align256(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 }  // namespace
@@ -277,6 +381,47 @@ extern "C" int mi_shard_bag_slots(const int64_t* table_offsets, int T, const voi
                        owner, n_ranks, local_ids, flags, chunk_cnt, n_chunks, err);
   hipLaunchKernelGGL(bag_slots_kernel, grid, dim3(SB_BLOCK), 0, s, flags, chunk_cnt, (int) n_bags, n_chunks, (int) cap,
                      row_of_bag, bag_of_row, cnt, err);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" size_t mi_shard_bag_bucket_workspace_bytes(int64_t n_bags, int n_ranks) {
+  return align256((size_t) mi_cdiv(n_bags > 0 ? n_bags : 1, SB_BLOCK) * n_ranks * 4);
+}
+
+extern "C" int mi_shard_bag_bucket(const int64_t* table_offsets, int T, const void* ids, int idx_bits, int bag_len,
+                                   int64_t n_bags, int rank, int n_ranks, int64_t cap, int64_t cap_ids,
+                                   const int32_t* row_of_bag, const int32_t* cnt, int32_t* send_ids, int64_t* send_off,
+                                   void* workspace, size_t workspace_bytes, int32_t* err, void* stream) {
+  const char* who = "mi_shard_bag_bucket";
+  MI_REQUIRE(table_offsets && ids && row_of_bag && cnt && send_ids && send_off && workspace, "%s: null pointer", who);
+  MI_REQUIRE(T >= 1 && bag_len >= 1 && n_bags >= 1 && n_bags % T == 0 && n_bags < ((int64_t) 1 << 30),
+             "%s: bad T / bag_len / n_bags", who);
+  MI_REQUIRE(idx_bits == 32 || idx_bits == 64, "%s: idx_bits must be 32 or 64", who);
+  MI_REQUIRE(n_ranks >= 1 && n_ranks <= 65535 && rank >= 0 && rank < n_ranks, "%s: bad rank / n_ranks", who);
+  MI_REQUIRE(cap >= 1 && cap * n_ranks < ((int64_t) 1 << 31) && cap_ids >= 1 && cap_ids * n_ranks < ((int64_t) 1 << 31),
+             "%s: capacity out of range", who);
+  if (workspace_bytes < mi_shard_bag_bucket_workspace_bytes(n_bags, n_ranks)) {
+    mi_set_error("%s: workspace %zu < %zu", who, workspace_bytes, mi_shard_bag_bucket_workspace_bytes(n_bags, n_ranks));
+    return MI_ERR_WORKSPACE;
+  }
+  const int n_chunks = (int) mi_cdiv(n_bags, SB_BLOCK);
+  int32_t* chunk_ids = (int32_t*) workspace;
+  hipStream_t s = (hipStream_t) stream;
+  const dim3 grid(n_chunks, n_ranks);
+  // every slot of the id blocks starts as a padding id; the kernels below write the live ones
+  MI_HIP(hipMemsetAsync(send_ids, 0xFF, (size_t) n_ranks * cap_ids * 4, s));
+  if (idx_bits == 32) {
+    hipLaunchKernelGGL(bag_idcount_kernel<int32_t>, grid, dim3(SB_BLOCK), 0, s, table_offsets, T, ids, bag_len, (int) n_bags,
+                       n_ranks, row_of_bag, chunk_ids, n_chunks);
+    hipLaunchKernelGGL(bag_bucket_kernel<int32_t>, grid, dim3(SB_BLOCK), 0, s, table_offsets, T, ids, bag_len, (int) n_bags,
+                       n_ranks, rank, (int) cap, cap_ids, row_of_bag, cnt, chunk_ids, n_chunks, send_ids, send_off, err);
+  } else {
+    hipLaunchKernelGGL(bag_idcount_kernel<int64_t>, grid, dim3(SB_BLOCK), 0, s, table_offsets, T, ids, bag_len, (int) n_bags,
+                       n_ranks, row_of_bag, chunk_ids, n_chunks);
+    hipLaunchKernelGGL(bag_bucket_kernel<int64_t>, grid, dim3(SB_BLOCK), 0, s, table_offsets, T, ids, bag_len, (int) n_bags,
+                       n_ranks, rank, (int) cap, cap_ids, row_of_bag, cnt, chunk_ids, n_chunks, send_ids, send_off, err);
+  }
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -651,6 +651,18 @@ def shard_bag_slots(toffs, T, ids, bag_len, n_bags, n_parts, owner, n_ranks, cap
               _stream())
 
 
+def shard_bag_bucket_workspace_bytes(n_bags, n_ranks):
+    return int(_lib.load().mi_shard_bag_bucket_workspace_bytes(n_bags, n_ranks))
+
+
+def shard_bag_bucket(toffs, T, ids, bag_len, n_bags, rank, n_ranks, cap, cap_ids, row_of_bag, cnt, send_ids, send_off,
+                     workspace, err=None):
+    """This rank's ids bucketed by owner, as the owners' local rows in CSR blocks; see mi_shard_bag_bucket."""
+    _need_cuda(toffs, ids, row_of_bag, cnt, send_ids, send_off, workspace, err)
+    _lib.call('mi_shard_bag_bucket', _p(toffs), T, _p(ids), _idx_bits(ids), bag_len, n_bags, rank, n_ranks, cap, cap_ids,
+              _p(row_of_bag), _p(cnt), _p(send_ids), _p(send_off), _p(workspace), workspace.numel(), _p(err), _stream())
+
+
 def shard_bag_gather(weights, ltoffs, T, local_ids, bag_len, n_bags, n_parts, cap, bag_of_row, cnt, out_rows):
     _lib.call('mi_shard_bag_gather', _p(weights), _p(ltoffs), T, weights.shape[1], _p(local_ids), bag_len, n_bags,
               n_parts, cap, _p(bag_of_row), _p(cnt), _p(out_rows), _stream())

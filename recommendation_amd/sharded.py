@@ -161,6 +161,8 @@ class RcclComm(object):
             _lib.call('mi_a2a_pooled', self._h, inp.data_ptr(), out.data_ptr(), n, self._stream())
         elif inp.dtype == torch.int32:
             _lib.call('mi_a2a_indices', self._h, inp.data_ptr(), out.data_ptr(), n, self._stream())
+        elif inp.dtype == torch.int64:          # as pairs of int32
+            _lib.call('mi_a2a_indices', self._h, inp.data_ptr(), out.data_ptr(), 2 * n, self._stream())
         else:
             raise ops.MiError("RcclComm.all_to_all: int32 or float32 blocks only")
 

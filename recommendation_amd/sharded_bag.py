@@ -14,7 +14,14 @@ r = table_offsets[t] + id lives on rank r % N as local row r / N, and a synchron
             C. all-to-all of the blocks
             owner: sort-by-row + fused optimizer on its local rows (gradient rows read in place)
 
-Three collectives of fixed size, nothing on the host waits for the device.  ``cap`` =
+``id_exchange='bucketed'`` replaces A by an all-to-all of the ids bucketed by owner (the reference's workers ask
+each parameter server only for the rows it holds, model_trainer.py:124-136): the requester sends owner p the CSR
+form of "my bags you contribute to" - your ids as YOUR local rows, int32, packed in bag order, and the first id of
+every slot - 4 bytes an id + 8 per (bag, owner) instead of 8*N bytes an id; the owner then runs the library's
+ordinary CSR embedding bag (mi_embag_fwd / mi_embag_bwd_prepare with offsets) over its local rows: no owner-side
+slot work at all.  ``cap_ids`` = capacity_factor * B*T*L / N ids per rank pair.
+
+Three (bucketed: four) collectives of fixed size, nothing on the host waits for the device.  ``cap`` =
 capacity_factor * B*T / N rows per rank pair (one-id bags; all B*T for bags of several ids, which
 nearly every owner contributes to).  A pair that needs more raises MI_IDERR_CAPACITY in the error
 word (checked by ``check()``): its surplus bags would contribute nothing, so the step is invalid.
@@ -61,7 +68,34 @@ class HipBagBackend(object):
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
     def slots_workspace(self, n_bags, n_parts):
-        return self.zeros((max(ops.shard_bag_slots_workspace_bytes(n_bags, n_parts), 1),), torch.uint8)
+        n = max(ops.shard_bag_slots_workspace_bytes(n_bags, n_parts), ops.shard_bag_bucket_workspace_bytes(n_bags, n_parts))
+        return self.zeros((max(n, 1),), torch.uint8)
+
+    # bucketed id exchange: sender side, then the owner's side as the ordinary CSR embedding bag on its local rows
+    def bucket(self, ids, n_bags, cap, cap_ids, row_of_bag, cnt, send_ids, send_off, ws):
+        ops.shard_bag_bucket(self.toffs, self.T, ids, self.L, n_bags, self.rank, self.world, cap, cap_ids, row_of_bag, cnt,
+                             send_ids, send_off, ws, self.err)
+
+    def _one_table(self):
+        if getattr(self, '_toffs1', None) is None:
+            self._toffs1 = ops.table_offsets([max(self.local_rows, 1)], self.device)
+        return self._toffs1
+
+    def gather_csr(self, recv_ids, recv_off, out_rows):
+        ops.embag_fwd(self.W, self._one_table(), 1, recv_ids, offsets=recv_off, out=out_rows.view(-1, self.dim),
+                      out_ld=self.dim, err=self.err)
+
+    def update_csr(self, recv_ids, recv_off, grad_rows, lr, eps):
+        if self._plan is None or self._plan.offsets is not recv_off or self._plan.n_entries != recv_ids.numel():
+            self._plan = ops.SortedPlan(self._one_table(), 1, max(self.local_rows, 1), recv_ids, offsets=recv_off,
+                                        runs=False)
+        else:
+            self._plan.prepare(recv_ids)
+        g = grad_rows.view(-1, self.dim)
+        if self.opt == 'sgd':
+            ops.bwd_apply_sgd(self._plan, g, self.W, lr)
+        else:
+            ops.bwd_apply_adagrad_rowwise(self._plan, g, self.W, self.state, lr, eps)
 
     def owner_slots(self, ids_all, n_bags, cap, local_ids, row_of_bag, bag_of_row, cnt, ws):
         ops.shard_bag_slots(self.toffs, self.T, ids_all, self.L, n_bags, self.world, self.rank, self.world, cap,
@@ -97,9 +131,13 @@ class HipBagBackend(object):
 
 class ShardedEmbeddingBag(object):
     def __init__(self, rows_per_table, dim, bag_len, device, opt='adagrad_rowwise', lr=1e-2, eps=1e-8, seed=0,
-                 init_scale=0.05, capacity_factor=2.0, comm=None, backend=None, rank=None, world=None):
+                 init_scale=0.05, capacity_factor=2.0, comm=None, backend=None, rank=None, world=None,
+                 id_exchange='all_gather'):
         if opt not in _OPT:
             raise ValueError("opt must be one of %s" % sorted(_OPT))
+        if id_exchange not in ('all_gather', 'bucketed'):
+            raise ValueError("id_exchange must be 'all_gather' or 'bucketed'")
+        self.bucketed = id_exchange == 'bucketed' 
         self.comm = comm if comm is not None else (TorchComm() if rank is None else None)
         self.rank = self.comm.rank if rank is None else rank
         self.world = self.comm.world if world is None else world
@@ -133,6 +171,11 @@ class ShardedEmbeddingBag(object):
             return n_bags                      # bags of several ids: nearly every owner contributes to every bag
         return min(n_bags, int(self.capacity_factor * n_bags / self.world) + 64)
 
+    def id_capacity(self, B):
+        """Ids one rank pair may exchange in a step (bucketed id exchange)."""
+        n = B * self.T * self.L
+        return n if self.world == 1 else min(n, int(self.capacity_factor * n / self.world) + 64)
+
     # -- buffers ------------------------------------------------------------------------------
     def _buffers(self, ids):
         B = ids.shape[0]
@@ -144,10 +187,17 @@ class ShardedEmbeddingBag(object):
         n_bags = B * T
         self.n_bags, self.cap = n_bags, self.capacity(B)
         cap = self.cap
-        self.ids_all = be.zeros((N, B, T, L), ids.dtype)
-        self.local_ids = be.zeros((N * n_bags, L), i32)
-        self.own_row_of_bag, self.own_bag_of_row = be.zeros((N, n_bags), i32), be.zeros((N * cap,), i32)
-        self.own_cnt = be.zeros((N,), i32)
+        if self.bucketed:
+            self.cap_ids = self.id_capacity(B)
+            self.send_ids, self.recv_ids = be.zeros((N, self.cap_ids), i32), be.zeros((N * self.cap_ids,), i32)
+            self.send_off = be.zeros((N, cap), torch.int64)
+            self.recv_off = be.zeros((N * cap + 1,), torch.int64)
+            self.recv_off[N * cap] = N * self.cap_ids          # the closing offset of the CSR bags, set once
+        else:
+            self.ids_all = be.zeros((N, B, T, L), ids.dtype)
+            self.local_ids = be.zeros((N * n_bags, L), i32)
+            self.own_row_of_bag, self.own_bag_of_row = be.zeros((N, n_bags), i32), be.zeros((N * cap,), i32)
+            self.own_cnt = be.zeros((N,), i32)
         self.req_row_of_bag, self.req_bag_of_row = be.zeros((N, n_bags), i32), be.zeros((N * cap,), i32)
         self.req_cnt = be.zeros((N,), i32)
         self.ws = be.slots_workspace(n_bags, N)
@@ -157,9 +207,20 @@ class ShardedEmbeddingBag(object):
         self._key = key
 
     # -- the phases of a step (public so that a test can drive several ranks in lockstep) -------
+    def phase_bucket(self, ids):
+        """Bucketed id exchange, sender side: this rank's ids -> send_ids [N][cap_ids], send_off [N][cap] (two
+        all-to-alls into recv_ids / recv_off[:N*cap])."""
+        be = self.be
+        be.requester_slots(ids, self.n_bags, self.cap, self.req_row_of_bag, self.req_bag_of_row, self.req_cnt, self.ws)
+        be.bucket(ids, self.n_bags, self.cap, self.cap_ids, self.req_row_of_bag, self.req_cnt, self.send_ids,
+                  self.send_off, self.ws)
+
     def phase_owner_forward(self):
         """self.ids_all (exchange A done) -> self.rows_out [N][cap][D] (exchange B: all-to-all into rows_in)."""
         be = self.be
+        if self.bucketed:       # the received blocks ARE CSR bags over this rank's local rows
+            be.gather_csr(self.recv_ids, self.recv_off, self.rows_out)
+            return self.rows_out
         be.owner_slots(self.ids_all, self.n_bags, self.cap, self.local_ids, self.own_row_of_bag, self.own_bag_of_row,
                        self.own_cnt, self.ws)
         be.gather(self.local_ids, self.n_bags, self.cap, self.own_bag_of_row, self.own_cnt, self.rows_out)
@@ -168,7 +229,8 @@ class ShardedEmbeddingBag(object):
     def phase_combine(self, ids):
         """self.rows_in -> self.pooled [B][T*D]."""
         be = self.be
-        be.requester_slots(ids, self.n_bags, self.cap, self.req_row_of_bag, self.req_bag_of_row, self.req_cnt, self.ws)
+        if not self.bucketed:   # (bucketed: done before the id exchange)
+            be.requester_slots(ids, self.n_bags, self.cap, self.req_row_of_bag, self.req_bag_of_row, self.req_cnt, self.ws)
         be.combine(self.rows_in, self.req_row_of_bag, self.n_bags, self.pooled)
         return self.pooled
 
@@ -179,7 +241,10 @@ class ShardedEmbeddingBag(object):
 
     def phase_update(self):
         """self.grad_in -> fused sparse update of this rank's rows."""
-        self.be.update(self.local_ids, self.grad_in, self.own_row_of_bag, self.lr, self.eps)
+        if self.bucketed:
+            self.be.update_csr(self.recv_ids, self.recv_off, self.grad_in, self.lr, self.eps)
+        else:
+            self.be.update(self.local_ids, self.grad_in, self.own_row_of_bag, self.lr, self.eps)
         self.steps += 1
 
     # -- one step over torch.distributed --------------------------------------------------------
@@ -188,7 +253,12 @@ class ShardedEmbeddingBag(object):
         ids = ids.reshape(ids.shape[0], self.T, self.L).contiguous()
         self._buffers(ids)
         self._ids = ids
-        self.comm.all_gather(self.ids_all.view(-1), ids.view(-1))          # A
+        if self.bucketed:
+            self.phase_bucket(ids)
+            self.comm.all_to_all(self.recv_ids, self.send_ids.view(-1))                          # A: ids, by owner
+            self.comm.all_to_all(self.recv_off[:self.world * self.cap], self.send_off.view(-1))  # A: slot offsets
+        else:
+            self.comm.all_gather(self.ids_all.view(-1), ids.view(-1))      # A
         self.phase_owner_forward()
         self.comm.all_to_all(self.rows_in.view(-1), self.rows_out.view(-1))     # B
         return self.phase_combine(ids)
@@ -207,10 +277,19 @@ def lockstep_step(models, ids_list, grads):
     protocol and the kernels of ``forward`` / ``backward`` on a single GPU.  Returns the pooled outputs."""
     for m, ids in zip(models, ids_list):
         m._buffers(ids.reshape(ids.shape[0], m.T, m.L))
-    for m in models:                                      # exchange A
-        for s, ids in enumerate(ids_list):
-            m.ids_all[s].copy_(ids.reshape(ids.shape[0], m.T, m.L))
-        m.phase_owner_forward()
+    if models[0].bucketed:
+        for m, ids in zip(models, ids_list):
+            m.phase_bucket(ids.reshape(ids.shape[0], m.T, m.L).contiguous())
+        for o, mo in enumerate(models):                   # exchange A, bucketed: block o of every sender
+            for s, ms in enumerate(models):
+                mo.recv_ids.view(len(models), -1)[s].copy_(ms.send_ids[o])
+                mo.recv_off[:len(models) * mo.cap].view(len(models), -1)[s].copy_(ms.send_off[o])
+            mo.phase_owner_forward()
+    else:
+        for m in models:                                  # exchange A
+            for s, ids in enumerate(ids_list):
+                m.ids_all[s].copy_(ids.reshape(ids.shape[0], m.T, m.L))
+            m.phase_owner_forward()
     for s, ms in enumerate(models):                       # exchange B
         for o, mo in enumerate(models):
             ms.rows_in[o].copy_(mo.rows_out[s])

@@ -35,6 +35,36 @@ def slots(toffs, T, ids, L, n_bags, n_parts, owner, N, cap):
     return local_ids, row_of_bag, bag_of_row, cnt, overflow
 
 
+def bucket(toffs, T, ids, L, n_bags, rank, N, cap, cap_ids, row_of_bag):
+    """numpy statement of mi_shard_bag_bucket: (send_ids [N][cap_ids], send_off [N][cap], overflow)."""
+    ids = np.asarray(ids).reshape(n_bags, L).astype(np.int64)
+    toffs = np.asarray(toffs)
+    t = np.arange(n_bags) % T
+    base, rows = toffs[t][:, None], (toffs[t + 1] - toffs[t])[:, None]
+    valid = (ids >= 0) & (ids < rows)
+    g = base + np.where(valid, ids, 0)
+    send_ids = np.full((N, cap_ids), -1, np.int32)
+    send_off = np.zeros((N, cap), np.int64)
+    overflow = False
+    for p in range(N):
+        own = valid & (g % N == p)
+        pos, slots = 0, 0
+        for bag in range(n_bags):
+            r = int(row_of_bag[p][bag])
+            if r < 0:
+                continue
+            mine = (g[bag][own[bag]] // N).astype(np.int32)
+            send_off[p][r - p * cap] = rank * cap_ids + min(pos, cap_ids)
+            if pos + mine.size <= cap_ids:
+                send_ids[p][pos:pos + mine.size] = mine
+            else:
+                overflow = True
+            pos += mine.size
+            slots += 1
+        send_off[p][slots:] = rank * cap_ids + min(pos, cap_ids)
+    return send_ids, send_off, overflow
+
+
 class NumpyBagBackend(object):
     def __init__(self, rows_per_table, dim, bag_len, opt, rank, world):
         self.device = torch.device('cpu')
@@ -68,6 +98,44 @@ class NumpyBagBackend(object):
 
     def requester_slots(self, ids, n_bags, cap, row_of_bag, bag_of_row, cnt, ws):
         self._slots(ids, n_bags, self.world, -1, cap, None, row_of_bag, bag_of_row, cnt)
+
+    def bucket(self, ids, n_bags, cap, cap_ids, row_of_bag, cnt, send_ids, send_off, ws):
+        si, so, ov = bucket(self.toffs, self.T, ids.numpy(), self.L, n_bags, self.rank, self.world, cap, cap_ids,
+                            row_of_bag.numpy())
+        self.overflow |= ov
+        send_ids.copy_(torch.from_numpy(si))
+        send_off.copy_(torch.from_numpy(so))
+
+    def gather_csr(self, recv_ids, recv_off, out_rows):
+        W, ids, off = self.W.numpy(), recv_ids.numpy(), recv_off.numpy()
+        out = out_rows.numpy().reshape(-1, self.dim)
+        for i in range(off.size - 1):
+            acc = np.zeros(self.dim, np.float32)
+            for k in ids[off[i]:off[i + 1]]:
+                if k >= 0:
+                    acc = acc + W[k]
+            out[i] = acc
+
+    def update_csr(self, recv_ids, recv_off, grad_rows, lr, eps):
+        ids, off = recv_ids.numpy(), recv_off.numpy()
+        g = grad_rows.numpy().reshape(-1, self.dim)
+        W, st = self.W.numpy(), self.state.numpy()
+        bag = np.repeat(np.arange(off.size - 1), np.diff(off))
+        live = ids[off[0]:off[-1]] >= 0
+        rows, src = ids[off[0]:off[-1]][live], bag[live]
+        order = np.argsort(rows, kind='stable')
+        rows, src = rows[order], src[order]
+        uniq, start = np.unique(rows, return_index=True)
+        end = np.append(start[1:], rows.size)
+        for r, lo, hi in zip(uniq, start, end):
+            s = np.zeros(self.dim, np.float64)
+            for k in src[lo:hi]:
+                s += g[k]
+            if self.opt == 'sgd':
+                W[r] = (W[r] - lr * s).astype(np.float32)
+            else:
+                st[r] = np.float32(st[r] + np.mean(s * s))
+                W[r] = (W[r] - lr * s / (np.sqrt(st[r]) + eps)).astype(np.float32)
 
     def gather(self, local_ids, n_bags, cap, bag_of_row, cnt, out_rows):
         W, li = self.W.numpy(), local_ids.numpy().reshape(self.world, n_bags, self.L)

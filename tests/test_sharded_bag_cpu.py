@@ -34,14 +34,15 @@ def _full_table():
     return (np.random.default_rng(7).standard_normal((sum(ROWS), DIM)) * 0.1).astype(np.float32)
 
 
-def _rank_main(rank, world, port, opt, L, out_dir):
+def _rank_main(rank, world, port, opt, L, out_dir, exchange='all_gather'):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from numpy_bag_backend import NumpyBagBackend
         from recommendation_amd.sharded_bag import ShardedEmbeddingBag
         be = NumpyBagBackend(ROWS, DIM, L, opt, rank, world)
-        m = ShardedEmbeddingBag(ROWS, DIM, L, device='cpu', opt=opt, lr=LR, backend=be, capacity_factor=4.0)
+        m = ShardedEmbeddingBag(ROWS, DIM, L, device='cpu', opt=opt, lr=LR, backend=be, capacity_factor=4.0,
+                                id_exchange=exchange)
         m.load_weights(_full_table())
         pooled = []
         for step in range(STEPS):
@@ -53,10 +54,12 @@ def _rank_main(rank, world, port, opt, L, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,opt,L", [(2, "sgd", 1), (2, "adagrad_rowwise", 3), (3, "adagrad_rowwise", 1)])
-def test_sharded_bag_over_gloo_equals_single_process(tmp_path, world, opt, L):
+@pytest.mark.parametrize("world,opt,L,exchange", [(2, "sgd", 1, "all_gather"), (2, "adagrad_rowwise", 3, "all_gather"),
+                                                  (3, "adagrad_rowwise", 1, "all_gather"), (2, "adagrad_rowwise", 3, "bucketed"),
+                                                  (3, "sgd", 1, "bucketed")])
+def test_sharded_bag_over_gloo_equals_single_process(tmp_path, world, opt, L, exchange):
     from oracle import embedding as oe
-    mp.spawn(_rank_main, args=(world, _free_port(), opt, L, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(world, _free_port(), opt, L, str(tmp_path), exchange), nprocs=world, join=True)
     toffs = np.concatenate([[0], np.cumsum(ROWS)]).astype(np.int64)
     W = _full_table().astype(np.float64)
     st = np.zeros(W.shape[0])

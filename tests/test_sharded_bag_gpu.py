@@ -11,6 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
+from numpy_bag_backend import bucket as np_bucket  # noqa: E402
 from numpy_bag_backend import slots as np_slots  # noqa: E402
 from oracle import embedding as oe  # noqa: E402
 
@@ -67,11 +68,47 @@ def test_slots_bit_exact(dev, N, L, idt):
             assert bool(int(err.item()) & ops.MI_IDERR_CAPACITY) == overflow
 
 
+@pytest.mark.parametrize("N,L,idt", [(2, 1, np.int64), (8, 1, np.int32), (8, 5, np.int64), (3, 20, np.int32)])
+def test_bucketed_id_blocks_bit_exact(dev, N, L, idt):
+    """mi_shard_bag_bucket against its numpy statement: every owner's block of local rows and slot offsets, for
+    every sending rank; a too small id capacity is reported."""
+    from recommendation_amd import ops
+    rng = np.random.default_rng(6)
+    rows = [1000, 3, 50000, 17, 250]
+    T, B = len(rows), 777
+    n_bags = B * T
+    toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    td = torch.from_numpy(toffs).to(dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    ids = _ids(rng, B, rows, L, 'zipf', 0.2 if L > 1 else 0.0).astype(idt)
+    idd = torch.from_numpy(ids).to(dev)
+    cap = n_bags if L > 1 else n_bags // N + 400
+    for cap_ids in (n_bags * L, n_bags * L // N + 4000, 50):
+        for rank in (0, N - 1):
+            ws = torch.zeros(max(ops.shard_bag_slots_workspace_bytes(n_bags, N), ops.shard_bag_bucket_workspace_bytes(n_bags, N)),
+                             dtype=torch.uint8, device=dev)
+            err = ops.new_error_word(dev)
+            rb, br, cnt = torch.full((N, n_bags), -9, **i32), torch.full((N * cap,), -9, **i32), torch.full((N,), -9, **i32)
+            ops.shard_bag_slots(td, T, idd, L, n_bags, N, -1, N, cap, None, rb, br, cnt, ws, err)
+            send_ids = torch.full((N, cap_ids), 7, **i32)
+            send_off = torch.full((N, cap), -7, dtype=torch.int64, device=dev)
+            err2 = ops.new_error_word(dev)         # (the slots above may have run out of bag capacity on their own)
+            ops.shard_bag_bucket(td, T, idd, L, n_bags, rank, N, cap, cap_ids, rb, cnt, send_ids, send_off, ws, err2)
+            want_ids, want_off, overflow = np_bucket(toffs, T, ids, L, n_bags, rank, N, cap, cap_ids, rb.cpu().numpy())
+            assert bool(int(err2.item()) & ops.MI_IDERR_CAPACITY) == overflow
+            assert overflow == (cap_ids == 50)
+            assert np.array_equal(send_off.cpu().numpy(), want_off)
+            if not overflow:
+                assert np.array_equal(send_ids.cpu().numpy(), want_ids)
+
+
+@pytest.mark.parametrize("exchange", ["all_gather", "bucketed"])
 @pytest.mark.parametrize("N,L,dim,opt", [(2, 1, 128, "adagrad_rowwise"), (4, 1, 16, "sgd"), (8, 1, 128, "adagrad_rowwise"),
-                                         (8, 4, 128, "adagrad_rowwise"), (3, 2, 32, "sgd")])
-def test_lockstep_ranks_equal_the_single_gpu_embedding_bag(dev, N, L, dim, opt):
+                                         (8, 4, 128, "adagrad_rowwise"), (3, 2, 32, "sgd"), (8, 20, 64, "adagrad_rowwise")])
+def test_lockstep_ranks_equal_the_single_gpu_embedding_bag(dev, N, L, dim, opt, exchange):
     """Pooled rows of every rank == mi_embag_fwd on the full table (one-id bags: the same bits); after two
-    steps the union of the shards == the single-GPU sort-by-row update of the concatenated batch."""
+    steps the union of the shards == the single-GPU sort-by-row update of the concatenated batch.  With either id
+    exchange: the all-gather of ids, or the all-to-all of ids bucketed by owner."""
     from recommendation_amd import ops
     from recommendation_amd.sharded_bag import ShardedEmbeddingBag, lockstep_step
     rng = np.random.default_rng(11)
@@ -80,8 +117,8 @@ def test_lockstep_ranks_equal_the_single_gpu_embedding_bag(dev, N, L, dim, opt):
     toffs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
     total = int(toffs[-1])
     W0 = (rng.standard_normal((total, dim)) * 0.1).astype(np.float32)
-    models = [ShardedEmbeddingBag(rows, dim, L, dev, opt=opt, lr=lr, rank=r, world=N, capacity_factor=3.0)
-              for r in range(N)]
+    models = [ShardedEmbeddingBag(rows, dim, L, dev, opt=opt, lr=lr, rank=r, world=N, capacity_factor=3.0,
+                                  id_exchange=exchange) for r in range(N)]
     for m in models:
         m.load_weights(W0)
     Wd = torch.from_numpy(W0.copy()).to(dev)
@@ -126,7 +163,8 @@ def test_capacity_overflow_is_reported_not_hidden(dev):
         models[0].be.check()
 
 
-def test_forward_backward_over_rccl_world1_equals_lockstep(dev):
+@pytest.mark.parametrize("exchange", ["all_gather", "bucketed"])
+def test_forward_backward_over_rccl_world1_equals_lockstep(dev, exchange):
     import torch.distributed as dist
     from recommendation_amd.sharded_bag import ShardedEmbeddingBag, lockstep_step
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -136,8 +174,8 @@ def test_forward_backward_over_rccl_world1_equals_lockstep(dev):
         rng = np.random.default_rng(3)
         rows, L, dim, B = [1000, 3, 50000, 17], 2, 128, 300
         W0 = (rng.standard_normal((sum(rows), dim)) * 0.1).astype(np.float32)
-        a = ShardedEmbeddingBag(rows, dim, L, dev, lr=0.05)
-        b = ShardedEmbeddingBag(rows, dim, L, dev, lr=0.05, rank=0, world=1)
+        a = ShardedEmbeddingBag(rows, dim, L, dev, lr=0.05, id_exchange=exchange)
+        b = ShardedEmbeddingBag(rows, dim, L, dev, lr=0.05, rank=0, world=1, id_exchange=exchange)
         for m in (a, b):
             m.load_weights(W0)
         for step in range(3):
