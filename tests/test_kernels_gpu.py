@@ -404,7 +404,9 @@ def test_fused_sparse_updates(dev, opt):
     are fed the device's own run sums (same kernel template, same fixed order, so bitwise the
     sums the fused kernel forms) and every updated buffer must agree to 1e-6: Adam divides by
     sqrt(v)+eps and v is quadratic in the sum, so comparing through an independently rounded
-    fp64 sum would test fp32 conditioning, not the kernel."""
+    fp64 sum would test fp32 conditioning, not the kernel.  That independent comparison is made as
+    well - the oracle's OWN fp64 run sums through the same formulas, every buffer to 1e-5 (achieved
+    errors are printed) - so that no part of the fused kernel is only compared with itself."""
     from recommendation_amd import ops
     rng = np.random.default_rng(7)
     dim = 16
@@ -420,33 +422,43 @@ def test_fused_sparse_updates(dev, opt):
     want = oe.row_grads(toffs, T, ids, grad, dim, bag_len=L)
     assert sorted(want) == sorted(grads)
     wr = w.astype(np.float64)
+    wi = w.astype(np.float64)                      # the independent evaluation: the oracle's own sums
     lr, b1, b2, eps = 0.05, 0.9, 0.999, 1e-8
     TOL = 2e-6
     if opt == "sgd":
         ops.bwd_apply_sgd(plan, g, wd, lr)
         oe.apply_sgd(wr, grads, lr)
+        oe.apply_sgd(wi, want, lr)
     elif opt == "adagrad_rowwise":
         st = rng.random(total).astype(np.float32)
         std = torch.from_numpy(st.copy()).to(dev)
         ops.bwd_apply_adagrad_rowwise(plan, g, wd, std, lr, eps)
-        sr = st.astype(np.float64)
+        sr, si = st.astype(np.float64), st.astype(np.float64)
         oe.apply_adagrad_rowwise(wr, sr, grads, lr, eps)
+        oe.apply_adagrad_rowwise(wi, si, want, lr, eps)
         assert rel_err(std.cpu().numpy(), sr) <= TOL
+        held("fused %s state vs the oracle's own sums" % opt, rel_err(std.cpu().numpy(), si), 1e-5)
     else:
         m0 = (rng.standard_normal((total, dim)) * 0.1).astype(np.float32)
         v0 = (rng.random((total, dim)) * 0.1).astype(np.float32)
         md, vd = torch.from_numpy(m0.copy()).to(dev), torch.from_numpy(v0.copy()).to(dev)
         lr_t = float(oe.adam_lr_t(lr, b1, b2, 3))
         mr, vr = m0.astype(np.float64), v0.astype(np.float64)
+        mi, vi = m0.astype(np.float64), v0.astype(np.float64)
         if opt == "adam_tf":
             ops.bwd_apply_adam_tf(plan, g, wd, md, vd, lr_t, b1, b2, eps)
             oe.apply_adam_tf(wr, mr, vr, grads, lr_t, b1, b2, eps)
+            oe.apply_adam_tf(wi, mi, vi, want, lr_t, b1, b2, eps)
         else:
             ops.bwd_apply_adam_dense_tf(plan, g, wd, md, vd, lr_t, b1, b2, eps)
             oe.apply_adam_tf(wr, mr, vr, grads, lr_t, b1, b2, eps, dense=True)
+            oe.apply_adam_tf(wi, mi, vi, want, lr_t, b1, b2, eps, dense=True)
         assert rel_err(md.cpu().numpy(), mr) <= TOL
         assert rel_err(vd.cpu().numpy(), vr) <= TOL
+        held("fused %s m vs the oracle's own sums" % opt, rel_err(md.cpu().numpy(), mi), 1e-5)
+        held("fused %s v vs the oracle's own sums" % opt, rel_err(vd.cpu().numpy(), vi), 1e-5)
     assert rel_err(wd.cpu().numpy(), wr) <= TOL
+    held("fused %s weights vs the oracle's own sums" % opt, rel_err(wd.cpu().numpy(), wi), 1e-5)
 
 
 @pytest.mark.parametrize("dim", [16, 128])
