@@ -91,14 +91,19 @@ class GraphedTrainStep(object):
     * the id error word is read every ``check_every`` replays (and by ``check()``) instead of in every
       ``features`` call: a bad id is never dereferenced meanwhile, it is just reported a few steps later.
     A batch of another shape (the ragged last batch of an epoch, recommend lists of another width) runs the eager step.  The tensors returned by
-    a replay are the graph's own output buffers: the next call overwrites them.  Single process only (the
-    data-parallel all-reduce is not captured: a captured collective could not be exercised by this build, which has
-    no second GPU to run two RCCL ranks on, so the data-parallel step stays eager)."""
+    a replay are the graph's own output buffers: the next call overwrites them.
 
-    def __init__(self, model, optimizer, columns, check_every=64):
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                torch.distributed.get_world_size() > 1:
-            raise RuntimeError("GraphedTrainStep is single-process; use train_step with a process group")
+    Data parallel (``process_group`` of more than one rank): the step is captured as TWO graphs around the
+    all-reduce - {encoders, forward, heads, loss, backward} and {schedule, Adam} - and a call is replay,
+    ``all_reduce`` of the flat gradient, division by the world size, replay: the same kernels and the same
+    collective as ``AdamOptimizer.minimize(process_group=...)``, so the same bits.  The collective itself stays
+    outside the graphs: torch.distributed's work objects are not capturable from Python, and this build has no
+    second GPU to exercise a captured RCCL call between two ranks."""
+
+    def __init__(self, model, optimizer, columns, check_every=64, process_group=None):
+        up = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.group = process_group
+        self.world = torch.distributed.get_world_size(process_group) if (up or process_group is not None) else 1
         m = self.model = model
         self.opt = optimizer
         self.check_every = int(check_every)
@@ -128,8 +133,16 @@ class GraphedTrainStep(object):
                 for dst, src in zip((params, optimizer.m, optimizer.v, self.sched), saved):
                     dst.copy_(src)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = self._body()
+            if self.world == 1:
+                with torch.cuda.graph(self.graph):
+                    self.out = self._body()
+            else:
+                self.gbuf = torch.empty_like(m.grad_arena())     # the averaged gradient the second graph reads
+                with torch.cuda.graph(self.graph):
+                    self.out = self._backward_part()
+                self.graph_apply = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_apply):
+                    self._apply_part(self.gbuf)
         finally:
             m._in_graph = False
 
@@ -138,7 +151,21 @@ class GraphedTrainStep(object):
         self.sched.copy_(torch.tensor([0.0, float(sch.b1p), float(sch.b2p)], dtype=torch.float32))
 
     def _body(self):
+        out = self._backward_part()
+        grad = self.model.grad_arena()
+        if self.world > 1:      # (warm-up of the data-parallel form: the ranks' gradients are NOT exchanged here)
+            grad = grad / self.world
+        self._apply_part(grad)
+        return out
+
+    def _apply_part(self, grad):
         m, opt = self.model, self.opt
+        ops.adam_schedule_step(self.sched, opt.learning_rate, opt.beta1, opt.beta2)
+        ops.adam_tf_dense(m.parameters().detach(), opt.m, opt.v, grad, 0.0, opt.beta1, opt.beta2, opt.epsilon,
+                          lr_dev=self.sched)
+
+    def _backward_part(self):
+        m = self.model
         features, labels = columns_to_features(self.static_in)
         label_tensor = m.input_to_one_hot_plus(labels, m.colour_count)
         fs = m.features(features)
@@ -147,13 +174,9 @@ class GraphedTrainStep(object):
         top_indices_real = top_indices.to(torch.int32)
         acc = m.accuracy(labels, top_indices_real, m.recommend_num)
         loss = m.loss(logits=last_layer, labels=label_tensor)
-        params = m.parameters()
         m.zero_grad()
         loss.backward()
         m.backward_done()
-        ops.adam_schedule_step(self.sched, opt.learning_rate, opt.beta1, opt.beta2)
-        ops.adam_tf_dense(params.detach(), opt.m, opt.v, m.grad_arena(), 0.0, opt.beta1, opt.beta2,
-                          opt.epsilon, lr_dev=self.sched)
         return acc, top_indices_real, loss.detach()
 
     def check(self):
@@ -166,7 +189,7 @@ class GraphedTrainStep(object):
         # any column of another shape than the captured one - a ragged last batch, or a batch whose recommend
         # lists have another width - takes the eager step; the device's schedule is brought back in line after it
         if len(ins) != len(self.static_in) or any(tuple(a.shape) != tuple(b.shape) for a, b in zip(ins, self.static_in)):
-            res = train_step(m, self.opt, columns)
+            res = train_step(m, self.opt, columns, process_group=self.group)
             self._sched_to_device()
             return res
         for dst, src in zip(self.static_in, ins):
@@ -174,6 +197,11 @@ class GraphedTrainStep(object):
         m._in_graph = True
         try:
             self.graph.replay()
+            if self.world > 1:
+                grad = m.grad_arena()
+                torch.distributed.all_reduce(grad, group=self.group)
+                torch.div(grad, self.world, out=self.gbuf)
+                self.graph_apply.replay()
         finally:
             m._in_graph = False
         self.opt._schedule.step()                   # the host's copy of the schedule (checkpoints, global_step)
@@ -219,9 +247,9 @@ def train(files, batch_size=300, last_step=5000, learning_rate=1e-4, device='cud
     while step < last_step:
         columns = iterator.get_next()
         step += 1
-        if graph and process_group is None:
+        if graph:
             if graphed is None:
-                graphed = GraphedTrainStep(m, optimizer, columns)
+                graphed = GraphedTrainStep(m, optimizer, columns, process_group=process_group)
             acc_res, _, _, loss_res, global_step_res = graphed(columns)
         else:
             acc_res, _, _, loss_res, global_step_res = train_step(m, optimizer, columns, process_group)
