@@ -834,6 +834,19 @@ int mi_din_lau_fwd(const mi_din_lau* net, const float* E, int64_t rows, const vo
                    int idx_bits, const int32_t* len, int64_t B, void* workspace, size_t workspace_bytes,
                    float* feat, int64_t ld_feat, int32_t* ids_all, int32_t* err, void* stream);
 
+/* The factored unit's forward as one launch (+ two small ones for the candidates' rows and the first layer's per-sample
+ * term; persistent workgroups, one sample at a time; rows, both hidden
+ * layers and the head stay in LDS between the layers): what mi_din_lau_fwd runs when mi_din_lau_fwd_fused_ok() - dim 64, hidden widths
+ * 128 / 64, L <= 112, factored first layer.  Writes the same A, H1, H2, a, ids_all and feat = [pooled | q] as
+ * mi_din_lau_build + mi_din_qterm_fwd + two mi_gemm_bf16 + mi_head_fwd + mi_din_lau_pool, bit for bit.
+ * No counterpart in the reference (r_model.py:68-80 is the nearest: a 6-id bag with uniform weights).
+ * W1f [128][128] bf16 (columns for k, then q*k), Wq [128][64], b1 [128], rowbias [B][128] (scratch: b1 + Wq q), W2 [64][128] bf16, b2 [64], w3 [65]. */
+int mi_din_lau_fwd_fused_ok(int dim, int h1, int h2, int L, int factored);
+int mi_din_lau_fwd_fused(const float* E, int64_t rows, const void* hist, const void* qid, int idx_bits,
+                         const int32_t* len, int64_t B, int L, const void* W1f, const float* Wq, const float* b1,
+                         const void* W2, const float* b2, const float* w3, void* A, void* H1, void* H2, float* a,
+                         int32_t* ids_all, float* feat, int64_t ld_feat, float* rowbias, int32_t* err, void* stream);
+
 /* Backward + Adam step of the unit's parameters from dfeat [B][ld_dfeat] = dL/d[pooled | q]; the workspace
  * and feat / ids_all as the forward of the same batch left them.  dE [B*(L+1)][dim] fp32: gradient of the
  * gathered rows, laid out like ids_all (input of the sparse update). */

@@ -148,6 +148,8 @@ _SIGNATURES = {
     'mi_din_lau_workspace_bytes': (c_size_t, [c_int64, POINTER(DinLau)]),
     'mi_din_lau_workspace_part': (c_int, [c_int64, POINTER(DinLau), c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     'mi_din_lau_fwd': (c_int, [POINTER(DinLau), P, c_int64, P, P, c_int, P, c_int64, P, c_size_t, P, c_int64, P, P, P]),
+    'mi_din_lau_fwd_fused_ok': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'mi_din_lau_fwd_fused': (c_int, [P, c_int64, P, P, c_int, P, c_int64, c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, P, P, P]),
     'mi_din_lau_bwd': (c_int, [POINTER(DinLau), c_int64, P, c_size_t, P, c_int64, P, c_int64, P, c_float, P, c_float,
                                c_float, c_float, P, P]),
     'mi_fm_fwd_sort_max_batch': (c_int, []),

@@ -311,6 +311,10 @@ extern "C" int mi_din_lau_fwd(const mi_din_lau* net, const float* E, int64_t row
   const int D = net->dim, H = net->h1, H2 = net->h2, L = net->L;
   const int64_t M = B * L;
   float* q = feat + D;  // feat = [pooled | q]
+  if (mi_din_lau_fwd_fused_ok(D, H, H2, L, net->factored))
+    // one launch, one workgroup per sample: the same values as the sequence below, bit for bit
+    return mi_din_lau_fwd_fused(E, rows, hist, qid, idx_bits, len, B, L, net->W1f, net->Wq, net->b1.w, net->W2.w_bf16,
+                                net->b2.w, net->w3.w, d.A, d.H1, d.H2, d.a, ids_all, feat, ld_feat, d.rowbias, err, stream);
   MI_TRY(mi_din_lau_build(E, rows, D, hist, qid, idx_bits, len, B, L, d.A, ids_all, q, ld_feat, d.a_cols, err, stream));
   if (net->factored) {
     // the q term of the first layer, once per sample (fp32), enters as a bias row per L positions

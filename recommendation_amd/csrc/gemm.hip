@@ -18,6 +18,7 @@
 // global -> LDS by DMA one tile ahead, retired with a counted vmcnt wait and ONE raw barrier per
 // K tile; inside a tile the fragment reads run three MFMA rows ahead of the MFMAs that use them.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -27,6 +28,9 @@ typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s4v* lds_s4v_ptr;
 
+#ifndef GEMM_PIPE
+#define GEMM_PIPE 1
+#endif
 constexpr int BK = 64;
 constexpr int SUB_BYTES = 128 * BK * 2;  // an operand tile is made of 128-row sub-tiles of 16 KiB
 
@@ -372,6 +376,100 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) void gemm_bf16_k
     stb.stage(k0_, Bs + (buf_) * B_BYTES, w);                        \
   } while (0)
 
+#if GEMM_PIPE
+  // The K loop as ONE stream of MFMA rows (a row = one A fragment against the FN resident B
+  // fragments) that runs across tile boundaries.  An A fragment is read RING rows before the MFMAs
+  // that use it; the barrier that hands over the next tile sits RING rows before the end of a tile,
+  // right after the last LDS read of the tile has been issued, so that the rows left over
+  // (their operands are in registers) cover the first reads of the next tile: no MFMA ever waits for
+  // a read that was issued after a barrier.  The buffer the barrier frees is restaged (tile kt+2) one
+  // DMA piece per row in the MFMAs' shadow, over the rest of this tile and the start of the next.
+  static_assert(STAGES == 2, "two staging buffers");
+  constexpr int A_PER = A_SUB * 16 / NWAVES, B_PER = B_SUB * 16 / NWAVES;
+  constexpr int ROWS = 2 * FM;             // MFMA rows of a K tile: k-step 0, then k-step 1
+  constexpr int RING = 4;                  // A fragments in flight ahead of the MFMAs
+  constexpr int RB = ROWS - RING;          // the row whose end holds the barrier
+  constexpr int TAIL = ROWS - 1 - RB;      // rows of a tile behind its barrier
+  constexpr int PPR = (PER_TILE + ROWS / 2 - 1) / (ROWS / 2);  // DMA pieces per row
+  constexpr int TAILP = TAIL * PPR < PER_TILE ? TAIL * PPR : PER_TILE;  // pieces of a tile issued in the tail rows
+  constexpr int HEAD_ROWS = (PER_TILE - TAILP + PPR - 1) / PPR;  // rows at the start of a tile that finish the staging of the next
+  static_assert(FM >= FN && ROWS % RING == 0 && HEAD_ROWS <= RB, "wave tile");
+  auto stage_piece = [&](int p, int64_t k0, int buf) {
+    if (p < A_PER) sta.stage_one(p, k0, As + buf * A_BYTES, w);
+    else stb.stage_one(p - A_PER, k0, Bs + buf * B_BYTES, w);
+  };
+  s8v fb[2][FN], fa[RING];
+  if (ktiles > 0) {
+    STAGE(0, 0);
+    if (ktiles > 1) {
+#pragma unroll
+      for (int p = 0; p < TAILP; ++p) stage_piece(p, kbeg + BK, 1);
+      wait_vmcnt<TAILP>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < FN; ++j) fb[0][j] = read_frag<B_TR>(Bs, wc * FN + j, 0, lane);
+#pragma unroll
+    for (int q = 0; q < RING; ++q) fa[q] = read_frag<A_TR>(As, wr * FM + q % FM, q / FM, lane);
+  }
+  int cur = 0;  // buffer of tile kt
+  // One K tile.  MORE1 / MORE2: tiles kt+1 / kt+2 exist - compile-time, so that the body is straight-line
+  // code (with a branch around each DMA piece the compiler drains ALL outstanding LDS reads at every
+  // join); the loop runs the steady state and the last two tiles are peeled.
+  auto tile = [&](int kt, auto more1_c, auto more2_c) {
+    constexpr bool MORE1 = decltype(more1_c)::value, MORE2 = decltype(more2_c)::value;
+    const int64_t k1 = kbeg + (int64_t) (kt + 1) * BK, k2 = k1 + BK;
+    const char* Ac = As + cur * A_BYTES;
+    const char* Bc = Bs + cur * B_BYTES;
+    const char* An = As + (cur ^ 1) * A_BYTES;
+    const char* Bn = Bs + (cur ^ 1) * B_BYTES;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int kk = r / FM, i = r % FM;
+      // the rest of tile kt+1 (its first pieces went out behind the previous barrier) ...
+      if (MORE1 && r <= RB) {
+#pragma unroll
+        for (int q = 0; q < PPR; ++q)
+          if (TAILP + r * PPR + q < PER_TILE) stage_piece(TAILP + r * PPR + q, k1, cur ^ 1);
+      }
+      // ... and the first pieces of tile kt+2 into the buffer this tile's barrier has freed
+      if (MORE2 && r > RB) {
+#pragma unroll
+        for (int q = 0; q < PPR; ++q)
+          if ((r - RB - 1) * PPR + q < TAILP) stage_piece((r - RB - 1) * PPR + q, k2, cur);
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        // first operand indexes the result's rows (kept in registers): n; second its columns (lanes): m
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, fb[kk][j]),
+                                                            __builtin_bit_cast(bf8v, fa[r % RING]), acc[i][j], 0, 0, 0);
+      if (MORE1 && r == RB) {
+        // every LDS read of this tile has been issued: once they are back the buffer may be
+        // overwritten; the wave's own DMA of tile kt+1 has landed at vmcnt(0), everybody's at the barrier
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[0][j] = read_frag<B_TR>(Bn, wc * FN + j, 0, lane);
+      }
+      if (r + RING < ROWS) fa[r % RING] = read_frag<A_TR>(Ac, wr * FM + (r + RING) % FM, (r + RING) / FM, lane);
+      else if (MORE1) fa[r % RING] = read_frag<A_TR>(An, wr * FM + (r + RING - ROWS) % FM, (r + RING - ROWS) / FM, lane);
+      // the B fragments of k-step 1: their registers are free once the previous tile's last row is done
+      if (r < FN) fb[1][r] = read_frag<B_TR>(Bc, wc * FN + r, 1, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    cur ^= 1;
+  };
+  {
+    int kt = 0;
+    for (; kt + 2 < ktiles; ++kt) tile(kt, std::true_type{}, std::true_type{});
+    if (kt + 1 < ktiles) tile(kt++, std::true_type{}, std::false_type{});
+    if (kt < ktiles) tile(kt, std::false_type{}, std::false_type{});
+  }
+#else
 #pragma unroll
   for (int s = 0; s < D; ++s)
     if (s < ktiles) STAGE(s, s);
@@ -432,6 +530,7 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) void gemm_bf16_k
     }
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
+#endif
 #undef STAGE
   // Epilogue.  In the accumulators a lane holds 4 consecutive n of ONE row m, and the 16 lanes of a
   // group hold 16 different rows: stored like that, every instruction touches 16 rows with 32 bytes

@@ -777,6 +777,21 @@ def din_lau_build(E, hist, qid, lengths, A, ids_all, q_out=None, err=None):
               _p(A), _p(ids_all), _p(q_out), q_out.stride(0) if q_out is not None else 0, A.shape[1], _p(err), _stream())
 
 
+def din_lau_fwd_fused_ok(dim, h1, h2, L, factored=True):
+    return bool(_lib.load().mi_din_lau_fwd_fused_ok(dim, h1, h2, L, int(factored)))
+
+
+def din_lau_fwd_fused(E, hist, qid, lengths, W1f, Wq, b1, W2, b2, w3, A, H1, H2, a, ids_all, feat, rowbias, err=None):
+    """The factored activation unit's forward in one launch (a workgroup per sample): A, H1, H2 (bf16), a (fp32),
+    ids_all and feat = [pooled | q], bit-identical to din_lau_build + din_qterm_fwd + two gemm_bf16 + head_fwd +
+    din_lau_pool."""
+    B, L = hist.shape
+    _need_cuda(E, hist, qid, lengths, W1f, Wq, b1, W2, b2, w3, A, H1, H2, a, ids_all, feat)
+    _lib.call('mi_din_lau_fwd_fused', _p(E), E.shape[0], _p(hist), _p(qid), _idx_bits(hist), _p(lengths), B, L, _p(W1f),
+              _p(Wq), _p(b1), _p(W2), _p(b2), _p(w3), _p(A), _p(H1), _p(H2), _p(a), _p(ids_all), _p(feat),
+              feat.stride(0), _p(rowbias), _p(err), _stream())
+
+
 def din_lau_pool(A, a, ids_all, dim, pooled):
     B, L1 = ids_all.shape
     _lib.call('mi_din_lau_pool', _p(A), A.shape[1], _p(a), _p(ids_all), B, L1 - 1, dim, _p(pooled), pooled.stride(0),

@@ -245,3 +245,57 @@ def _din_step_launch_by_launch(m, hist, qid, lengths, labels):
     m.plan.prepare(m.ids_all.view(-1))
     ops.bwd_apply_adagrad_rowwise(m.plan, q['dE'], m.E, m.E_acc, m.emb_lr, m.emb_eps, grad_ld=D)
     return m.loss
+
+
+@pytest.mark.parametrize("B,L,idx", [(64, 10, torch.int64), (32, 100, torch.int32), (8, 112, torch.int64), (8, 1, torch.int32)])
+def test_din_fused_forward_equals_the_separate_launches_bitwise(dev, B, L, idx):
+    """mi_din_lau_fwd_fused (one workgroup per sample, layers out of LDS) against mi_din_lau_build + mi_din_qterm_fwd +
+    two mi_gemm_bf16 + mi_head_fwd + mi_din_lau_pool on the same inputs: every output bit for bit, with empty
+    histories, masked positions (-1), ids out of range (reported, rows zero) and a candidate out of range."""
+    from recommendation_amd import ops
+    rows, D, H, H2 = 3000, 64, 128, 64
+    assert ops.din_lau_fwd_fused_ok(D, H, H2, L)
+    assert not ops.din_lau_fwd_fused_ok(D, H, H2, 113) and not ops.din_lau_fwd_fused_ok(D, H, H2, L, factored=False)
+    g = torch.Generator(device='cpu').manual_seed(11 + B)
+    f32 = dict(dtype=torch.float32, device=dev)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    E = (torch.randn((rows, D), generator=g) * 0.3).to(dev)
+    W1f = (torch.randn((H, 2 * D), generator=g) * 0.1).to(dev).to(torch.bfloat16)
+    Wq = (torch.randn((H, D), generator=g) * 0.1).to(dev)
+    b1 = (torch.randn((H,), generator=g) * 0.1).to(dev)
+    W2 = (torch.randn((H2, H), generator=g) * 0.1).to(dev).to(torch.bfloat16)
+    b2 = (torch.randn((H2,), generator=g) * 0.1).to(dev)
+    w3 = torch.zeros((H2 + 4,), **f32)
+    w3[:H2 + 1] = (torch.randn((H2 + 1,), generator=g) * 0.2).to(dev)
+    hist = torch.randint(0, rows, (B, L), generator=g)
+    hist[0, 0] = -1                      # a masked position inside the history
+    if B > 2 and L > 2:
+        hist[2, 1] = rows + 5            # out of range: reported, the row contributes nothing
+    qid = torch.randint(0, rows, (B,), generator=g)
+    qid[B - 1] = rows                    # candidate out of range: q = 0
+    lengths = torch.randint(0, L + 1, (B,), generator=g).to(torch.int32)
+    lengths[0] = L
+    if B > 2:
+        lengths[1] = 0                   # an empty history
+        lengths[2] = L
+    hist, qid, lengths = hist.to(idx).to(dev), qid.to(idx).to(dev), lengths.to(dev)
+    M = B * L
+
+    def outputs():
+        return dict(A=torch.full((M, 2 * D), 7.0, **bf), H1=torch.full((M, H), 7.0, **bf), H2=torch.full((M, H2), 7.0, **bf),
+                    a=torch.full((M,), 7.0, **f32), ids_all=torch.full((B, L + 1), 7, dtype=torch.int32, device=dev),
+                    feat=torch.full((B, 2 * D), 7.0, **f32), err=torch.zeros((1,), dtype=torch.int32, device=dev))
+    x, y = outputs(), outputs()
+    ops.din_lau_fwd_fused(E, hist, qid, lengths, W1f, Wq, b1, W2, b2, w3, x['A'], x['H1'], x['H2'], x['a'], x['ids_all'],
+                          x['feat'], torch.empty((B, H), **f32), err=x['err'])
+    rowbias = torch.empty((B, H), **f32)
+    ops.din_lau_build(E, hist, qid, lengths, y['A'], y['ids_all'], q_out=y['feat'][:, D:], err=y['err'])
+    ops.din_qterm_fwd(y['feat'][:, D:], Wq, b1, rowbias)
+    ops.gemm_bf16(y['A'], W1f, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=y['H1'], bias=rowbias, bias_rows=L)
+    ops.gemm_bf16(y['H1'], W2, ops.MI_EPI_BIAS_ACT, flags=ops.MI_EPI_RELU, out=y['H2'], bias=b2)
+    ops.head_fwd(y['H2'], w3[:H2], w3[H2:H2 + 1], None, 0.0, y['a'], None, None)
+    ops.din_lau_pool(y['A'], y['a'], y['ids_all'], D, y['feat'])
+    torch.cuda.synchronize()
+    for name in ('ids_all', 'err', 'A', 'H1', 'H2', 'a', 'feat'):
+        assert torch.equal(x[name], y[name]), name
+    assert int(x['err'][0]) != 0
