@@ -847,6 +847,22 @@ int mi_din_lau_fwd_fused(const float* E, int64_t rows, const void* hist, const v
                          const void* W2, const float* b2, const float* w3, void* A, void* H1, void* H2, float* a,
                          int32_t* ids_all, float* feat, int64_t ld_feat, float* rowbias, int32_t* err, void* stream);
 
+/* The data path of the factored unit's backward as one launch per sample (same conditions as the fused forward):
+ * from dfeat [B][ld_dfeat] = dL/d[pooled | q] and what the forward left (A, H1, H2, a, ids_all, feat) to
+ *   dZ2 [B*L][64], dZ1 [B*L][128] bf16 (what the weight-gradient contractions read),
+ *   dE [B*(L+1)][64] fp32: rows of the history positions complete; the candidate's row = dq_above + sum_j k_j * gp,
+ *     to which the caller adds S Wq (mi_din_qterm_bwd with dq_in = dq = that row),
+ *   S [B][128] = per-sample column sums of dZ1,
+ *   part [B][mi_din_lau_bwd_part_floats()] scratch and part_sums [slices][same]: partial sums over runs of samples of
+ *     [dL/dw3 (64) | dL/d(bias3) | 0 0 0 | dL/db2 (64)] (slices must cut B into equal runs: ceil(B / ceil(B / slices)) == slices).
+ * dZ2, dZ1 and the history rows of dE are bit-identical to mi_din_lau_pool_bwd + mi_head_bwd + the two masked
+ * mi_gemm_bf16 + mi_din_lau_scatter_fact; the sums are added in another order.  No counterpart in the reference. */
+int mi_din_lau_bwd_part_floats(void);
+int mi_din_lau_bwd_fused(int64_t B, int L, const void* A, const void* H1, const void* H2, const float* a,
+                         const int32_t* ids_all, const float* feat, int64_t ld_feat, const float* dfeat, int64_t ld_dfeat,
+                         const float* w3, const void* W2T, const void* W1fT, void* dZ2, void* dZ1, float* dE, float* S,
+                         float* part, int slices, float* part_sums, void* stream);
+
 /* Backward + Adam step of the unit's parameters from dfeat [B][ld_dfeat] = dL/d[pooled | q]; the workspace
  * and feat / ids_all as the forward of the same batch left them.  dE [B*(L+1)][dim] fp32: gradient of the
  * gathered rows, laid out like ids_all (input of the sparse update). */

@@ -150,6 +150,8 @@ _SIGNATURES = {
     'mi_din_lau_fwd': (c_int, [POINTER(DinLau), P, c_int64, P, P, c_int, P, c_int64, P, c_size_t, P, c_int64, P, P, P]),
     'mi_din_lau_fwd_fused_ok': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'mi_din_lau_fwd_fused': (c_int, [P, c_int64, P, P, c_int, P, c_int64, c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, P, P, P]),
+    'mi_din_lau_bwd_part_floats': (c_int, []),
+    'mi_din_lau_bwd_fused': (c_int, [c_int64, c_int, P, P, P, P, P, P, c_int64, P, c_int64, P, P, P, P, P, P, P, P, c_int, P, P]),
     'mi_din_lau_bwd': (c_int, [POINTER(DinLau), c_int64, P, c_size_t, P, c_int64, P, c_int64, P, c_float, P, c_float,
                                c_float, c_float, P, P]),
     'mi_fm_fwd_sort_max_batch': (c_int, []),

@@ -122,7 +122,8 @@ int cross_check(const char* who, const mi_cross_net* net, const void* x0, int64_
 // ---- DIN activation unit ------------------------------------------------------------------------
 struct DinWs {
   char *A, *dA, *H1, *dZ1, *H2, *dH2;
-  float *a, *da, *rowbias, *S, *dq, *qpart, *gWf, *gq, *slab;
+  float *a, *da, *rowbias, *S, *dq, *qpart, *gWf, *gq, *part, *part_sums, *slab;
+  int part_slices;
   size_t bytes;
   int vec_slices, a_cols;
 };
@@ -149,6 +150,12 @@ DinWs din_carve(void* ws, int64_t B, const mi_din_lau* n) {
     d.qpart = (float*) take((size_t) mi_din_qterm_part_floats(B, H, D) * 4);
     d.gWf = (float*) take((size_t) H * 2 * D * 4);
     d.gq = (float*) take((size_t) (D * H + H) * 4);
+    // per-sample sums of the fused backward, and their reduction to at most 256 runs of samples
+    int ps = (int) (B < 256 ? B : 256);
+    while (ps > 1 && mi_cdiv(B, mi_cdiv(B, ps)) != ps) --ps;
+    d.part_slices = ps;
+    d.part = (float*) take((size_t) B * mi_din_lau_bwd_part_floats() * 4);
+    d.part_sums = (float*) take((size_t) ps * mi_din_lau_bwd_part_floats() * 4);
   }
   const int64_t v = M / 64;
   d.vec_slices = (int) (v < 1 ? 1 : (v > 1024 ? 1024 : v));
@@ -346,6 +353,38 @@ extern "C" int mi_din_lau_bwd(const mi_din_lau* net, int64_t B, void* workspace,
   const Adam a{lr_t, lr_dev, beta1, beta2, eps, true};
   const float* q = feat + D;
   const float* dq_above = dfeat + D;  // what the layers above send to q directly
+  if (mi_din_lau_fwd_fused_ok(D, H, H2, L, net->factored)) {
+    // The data path in one launch per sample (dA and the weights' gradient da never reach HBM), then the weight
+    // steps from what it left: dZ2, dZ1, the per-sample sums S, and the head's / second bias' gradients as
+    // `part_slices` partial rows [w3 (H2 + 4) | b2 (H2)].
+    const int P = mi_din_lau_bwd_part_floats();
+    MI_TRY(mi_din_lau_bwd_fused(B, L, d.A, d.H1, d.H2, d.a, ids_all, feat, ld_feat, dfeat, ld_dfeat, net->w3.w,
+                                net->W2.w_bf16_t, net->W1fT, d.dH2, d.dZ1, dE, d.S, d.part, d.part_slices, d.part_sums,
+                                stream));
+    MI_TRY(mi_slab_adam(d.part_sums, d.part_slices, H2 + 4, P, net->w3.w, net->w3.m, net->w3.v, a.lr_t, a.lr_dev, a.b1, a.b2,
+                        a.eps, nullptr, net->w3.grad_out, stream));
+    MI_TRY(weight_step(net->W2, H2, H, d.dH2, H2, d.H1, H, M, d.slab, a, stream));
+    MI_TRY(mi_slab_adam(d.part_sums + H2 + 4, d.part_slices, H2, P, net->b2.w, net->b2.m, net->b2.v, a.lr_t, a.lr_dev, a.b1,
+                        a.b2, a.eps, nullptr, net->b2.grad_out, stream));
+    // d q (the candidate's row of dE, left as dq_above + sum_j k_j * gp) += S Wq; partials of q^T S (-> d Wa), sums of S (-> d b1)
+    float* dq_rows = dE + (int64_t) L * D;
+    MI_TRY(mi_din_qterm_bwd(q, ld_feat, d.S, net->Wq, B, H, D, dq_rows, (int64_t) (L + 1) * D, dq_rows, (int64_t) (L + 1) * D,
+                            d.qpart, stream));
+    const int64_t stride = (int64_t) D * H + H;
+    const int chunks = (int) (mi_din_qterm_part_floats(B, H, D) / stride);
+    MI_TRY(mi_slab_adam(d.qpart, chunks, stride, stride, nullptr, nullptr, nullptr, 0.f, nullptr, 0.f, 0.f, 0.f, nullptr, d.gq, stream));
+    MI_TRY(mi_slab_adam(d.gq + (size_t) D * H, 1, H, H, net->b1.w, net->b1.m, net->b1.v, a.lr_t, a.lr_dev, a.b1, a.b2, a.eps,
+                        nullptr, net->b1.grad_out, stream));
+    const int s = wgrad_splits(H, d.a_cols, M);
+    {
+      const mi_gemm_epilogue e = epi(MI_EPI_SLAB, 0, d.slab, d.a_cols);
+      MI_TRY(mi_gemm_bf16(1, 1, H, d.a_cols, M, d.dZ1, H, d.A, d.a_cols, s, &e, stream));
+    }
+    MI_TRY(mi_slab_adam(d.slab, s, (int64_t) H * d.a_cols, (int64_t) H * d.a_cols, nullptr, nullptr, nullptr, 0.f, nullptr, 0.f,
+                        0.f, 0.f, nullptr, d.gWf, stream));
+    return mi_din_w1_step(d.gWf, 1, (int64_t) H * d.a_cols, d.gq, 1, stride, H, D, net->W1.w, net->W1.m, net->W1.v, a.lr_t,
+                          a.lr_dev, a.b1, a.b2, a.eps, net->W1f, net->W1fT, net->Wq, net->WqT, net->W1.grad_out, stream);
+  }
   // the unit, output side first; data gradients with the OLD weights, then the weight steps
   MI_TRY(mi_din_lau_pool_bwd(d.A, d.a_cols, dfeat, ld_dfeat, ids_all, B, L, D, d.da, stream));
   MI_HIP(hipMemsetAsync(d.slab, 0, (size_t) d.vec_slices * (H2 + 4) * 4, (hipStream_t) stream));

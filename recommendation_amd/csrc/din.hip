@@ -119,7 +119,11 @@ __global__ __launch_bounds__(256) void din_pool_bwd_kernel(const unsigned short*
   if (ids_all[b * (L + 1) + j] >= 0) {
     const float4 d = *reinterpret_cast<const float4*>(dpooled + b * ld + c * 4);
     const ushort4 u = *reinterpret_cast<const ushort4*>(A + item * a_cols + k_off + c * 4);
-    s = d.x * mi_bf2f(u.x) + d.y * mi_bf2f(u.y) + d.z * mi_bf2f(u.z) + d.w * mi_bf2f(u.w);
+    // explicit roundings (the fused backward computes the same value and is held to these bits)
+    s = __fmul_rn(d.x, mi_bf2f(u.x));
+    s = fmaf(d.y, mi_bf2f(u.y), s);
+    s = fmaf(d.z, mi_bf2f(u.z), s);
+    s = fmaf(d.w, mi_bf2f(u.w), s);
   }
 #pragma unroll
   for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
@@ -214,10 +218,10 @@ __global__ __launch_bounds__(256) void din_scatter_fact_kernel(const unsigned sh
       float4 dk = make_float4(0.f, 0.f, 0.f, 0.f);
       if (on[t]) {
         const float4 k = cv(uk[t]), gk = cv(ugk[t]), gp = cv(ugp[t]);
-        dk.x = fmaf(w[t], dp.x, gk.x + q.x * gp.x);
-        dk.y = fmaf(w[t], dp.y, gk.y + q.y * gp.y);
-        dk.z = fmaf(w[t], dp.z, gk.z + q.z * gp.z);
-        dk.w = fmaf(w[t], dp.w, gk.w + q.w * gp.w);
+        dk.x = fmaf(w[t], dp.x, fmaf(q.x, gp.x, gk.x));
+        dk.y = fmaf(w[t], dp.y, fmaf(q.y, gp.y, gk.y));
+        dk.z = fmaf(w[t], dp.z, fmaf(q.z, gp.z, gk.z));
+        dk.w = fmaf(w[t], dp.w, fmaf(q.w, gp.w, gk.w));
         dq.x = fmaf(k.x, gp.x, dq.x); dq.y = fmaf(k.y, gp.y, dq.y);
         dq.z = fmaf(k.z, gp.z, dq.z); dq.w = fmaf(k.w, gp.w, dq.w);
       }

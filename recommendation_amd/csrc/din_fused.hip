@@ -328,6 +328,345 @@ __global__ __launch_bounds__(256, 3) void din_lau_fwd_fused_kernel(FusedArgs p) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Backward of the unit's DATA path, one workgroup per sample: from dL/d[pooled | q] to the gradient of every
+// gathered row, through both hidden layers on the matrix cores out of LDS.  What it leaves in HBM is what the
+// weight-gradient contractions read (dZ2, dZ1 beside the forward's A and H1) and the per-sample sums the small
+// parameters need; dA and the per-position weights' gradient never reach HBM.
+//   da_j   = <dpooled, k_j>                                  (0 on masked positions)
+//   dZ2    = da_j w3 where H2 > 0                             [L][FH2]
+//   dZ1    = (dZ2 W2) where H1 > 0                            [L][FH1]
+//   [gk | gp] = dZ1 W1f  (rounded to bf16 as the separate launches store it)
+//   d k_j  = a_j dpooled + gk + q * gp;   d q = dq_above + sum_j k_j * gp   (+ S Wq, added by mi_din_qterm_bwd)
+//   S = column sums of dZ1,  part = [sum_j da_j H2[j] | sum_j da_j | 0 0 0 | column sums of dZ2]
+constexpr int FPART = FH2 + 4 + FH2;
+struct FusedBwdArgs {
+  int64_t B;
+  int L;
+  const unsigned short* A;    // [B*L][2*FD]: only the k block is read
+  const unsigned short* H1;   // [B*L][FH1]
+  const unsigned short* H2;   // [B*L][FH2]
+  const float* a;             // [B*L]
+  const int32_t* ids_all;     // [B][L+1]
+  const float* feat;          // [B][ld_feat] = [pooled | q]
+  int64_t ld_feat;
+  const float* dfeat;         // [B][ld_dfeat] = dL/d[pooled | q]
+  int64_t ld_dfeat;
+  const float* w3;            // [FH2] (+ bias)
+  const unsigned short* W2T;  // [FH1][FH2] bf16
+  const unsigned short* W1fT; // [2*FD][FH1] bf16
+  unsigned short* dZ2;        // [B*L][FH2]
+  unsigned short* dZ1;        // [B*L][FH1]
+  float* dE;                  // [B*(L+1)][FD]
+  float* S;                   // [B][FH1]
+  float* part;                // [B][FPART]: [sum_j da_j H2[j] | sum_j da_j | 0 0 0 | column sums of dZ2]
+};
+
+struct FusedBwdLds {
+  char h1[2][IMG];   // H1, then dZ1 in place (two 64-column images); then the d k rows (fp32, [FROWS][FD])
+  char z2[IMG];      // dZ2; then gp (bf16, [FROWS][FD])
+  float da[FROWS];
+  float a[FROWS];
+  int live[FROWS];
+  float red[4][FH1];  // cross-wave partial sums
+  float misc[4];
+};
+
+__device__ __forceinline__ float bfl(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bfh(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+template <int DUMMY>
+__global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) FusedBwdLds S;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int L = p.L;
+  const int64_t b = blockIdx.x;
+  const int64_t row0 = b * L;
+  // --- everything the sample needs from HBM, requested at once: 16-byte chunks, whole rows contiguous ---
+  // k block and H2: chunk c8 = t & 7 (8 columns) of rows (t >> 3) + 32 s;  H1: chunk c16 = t & 15 of rows (t >> 4) + 16 s
+  const int c8 = t & 7, r8 = t >> 3, c16 = t & 15, r16 = t >> 4;
+  uint4 kreg[4], h2reg[4], h1reg[FFRAGS];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int r = r8 + 32 * s;
+    kreg[s] = h2reg[s] = make_uint4(0u, 0u, 0u, 0u);
+    if (r < L) {
+      kreg[s] = *reinterpret_cast<const uint4*>(p.A + (row0 + r) * (2 * FD) + c8 * 8);
+      h2reg[s] = *reinterpret_cast<const uint4*>(p.H2 + (row0 + r) * FH2 + c8 * 8);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < FFRAGS; ++s) {
+    const int r = r16 + 16 * s;
+    h1reg[s] = r < L ? *reinterpret_cast<const uint4*>(p.H1 + (row0 + r) * FH1 + c16 * 8) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (t < FROWS) {
+    S.a[t] = t < L ? p.a[row0 + t] : 0.f;
+    S.live[t] = t < L ? (p.ids_all[b * (L + 1) + t] >= 0 ? 1 : 0) : 0;
+  }
+  // dpooled and w3 for the thread's 8 columns; weights' fragments (16 outputs, 32 inputs: lane l holds row l & 15,
+  // inputs 8 (l >> 4) .. + 7).  Layer 2 back: wave w owns outputs [32 w, 32 w + 32) of dH1; layer 1 back: outputs
+  // [16 w, 16 w + 16) of gk AND of gp, so that one lane holds both halves of its columns.
+  const float4 dp0 = *reinterpret_cast<const float4*>(p.dfeat + b * p.ld_dfeat + c8 * 8);
+  const float4 dp1 = *reinterpret_cast<const float4*>(p.dfeat + b * p.ld_dfeat + c8 * 8 + 4);
+  const float4 w30 = *reinterpret_cast<const float4*>(p.w3 + c8 * 8);
+  const float4 w31 = *reinterpret_cast<const float4*>(p.w3 + c8 * 8 + 4);
+  s8v wb2[2][2], wb1[2][4];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      wb2[jj][kk] = *reinterpret_cast<const s8v*>(p.W2T + ((2 * w + jj) * 16 + (lane & 15)) * FH2 + kk * 32 + 8 * (lane >> 4));
+  const int d0 = w * 16 + (lane >> 4) * 4;  // the lane's four columns of d k
+  const float4 dpd = *reinterpret_cast<const float4*>(p.dfeat + b * p.ld_dfeat + d0);
+  const float4 qd = *reinterpret_cast<const float4*>(p.feat + b * p.ld_feat + FD + d0);
+
+  // --- da_j = <dpooled, k_j>: four columns at a time, then the tree of the separate kernel (its 16 lanes of 4
+  // columns are this kernel's 8 lanes of 2 x 4) ---
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4 u = kreg[s];
+    float lo = __fmul_rn(dp0.x, bfl(u.x));
+    lo = fmaf(dp0.y, bfh(u.x), lo);
+    lo = fmaf(dp0.z, bfl(u.y), lo);
+    lo = fmaf(dp0.w, bfh(u.y), lo);
+    float hi = __fmul_rn(dp1.x, bfl(u.z));
+    hi = fmaf(dp1.y, bfh(u.z), hi);
+    hi = fmaf(dp1.z, bfl(u.w), hi);
+    hi = fmaf(dp1.w, bfh(u.w), hi);
+    lo = __fadd_rn(lo, hi);
+    lo += __shfl_xor(lo, 1, 64);
+    lo += __shfl_xor(lo, 2, 64);
+    lo += __shfl_xor(lo, 4, 64);
+    const int r = r8 + 32 * s;
+    if (c8 == 0 && r < FROWS) S.da[r] = lo;  // masked positions and the rows behind the history hold k = 0: da = 0
+  }
+  // H1 into LDS as the operand images
+#pragma unroll
+  for (int s = 0; s < FFRAGS; ++s)
+    *reinterpret_cast<uint4*>(S.h1[c16 >> 3] + img_off(r16 + 16 * s, c16 & 7)) = h1reg[s];
+  lds_barrier();
+  // (requested now that the registers of the H1 chunks are free; needed two phases further on)
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      wb1[jj][kk] = *reinterpret_cast<const s8v*>(p.W1fT + ((w + 4 * jj) * 16 + (lane & 15)) * FH1 + kk * 32 + 8 * (lane >> 4));
+  // --- dZ2 = da_j w3 where H2 > 0: by the threads that hold the H2 chunks, straight to HBM and into the operand
+  // image; the same pass leaves the thread's share of the sums over the sample's rows ---
+  float sw3[8], sb2[8], sda = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sw3[i] = sb2[i] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int r = r8 + 32 * s;
+    if (r < FROWS) {  // uniform per wave-instruction group of rows; rows >= L hold zeros
+      const float g = S.da[r];
+      const uint4 h = h2reg[s];
+      const uint32_t hu[4] = {h.x, h.y, h.z, h.w};
+      const float wv[8] = {w30.x, w30.y, w30.z, w30.w, w31.x, w31.y, w31.z, w31.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float h0 = bfl(hu[i]), h1v = bfh(hu[i]);
+        const unsigned short z0 = h0 > 0.f ? mi_f2bf(g * wv[2 * i]) : (unsigned short) 0;
+        const unsigned short z1 = h1v > 0.f ? mi_f2bf(g * wv[2 * i + 1]) : (unsigned short) 0;
+        o[i] = (uint32_t) z0 | ((uint32_t) z1 << 16);
+        sw3[2 * i] = fmaf(g, h0, sw3[2 * i]);
+        sw3[2 * i + 1] = fmaf(g, h1v, sw3[2 * i + 1]);
+        sb2[2 * i] += bfl(o[i]);
+        sb2[2 * i + 1] += bfh(o[i]);
+      }
+      if (c8 == 0) sda += g;
+      const uint4 z = make_uint4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<uint4*>(S.z2 + img_off(r, c8)) = z;
+      if (r < L) *reinterpret_cast<uint4*>(p.dZ2 + (row0 + r) * FH2 + c8 * 8) = z;
+    }
+  }
+  // the sums over the rows: lanes with the same chunk (lane bits 3-5), then the four waves
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      sw3[i] += __shfl_xor(sw3[i], o, 64);
+      sb2[i] += __shfl_xor(sb2[i], o, 64);
+    }
+  }
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) sda += __shfl_xor(sda, o, 64);
+  if (lane < 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      S.red[w][lane * 8 + i] = sw3[i];
+      S.red[w][64 + lane * 8 + i] = sb2[i];
+    }
+    if (lane == 0) S.misc[w] = sda;
+  }
+  lds_barrier();  // dZ2 image and the partial sums are there
+  if (t < 128) {
+    const float v = (S.red[0][t] + S.red[1][t]) + (S.red[2][t] + S.red[3][t]);
+    p.part[b * FPART + (t < 64 ? t : t + 4)] = v;
+  } else if (t < 132) {  // the head's bias gradient (sum of da) and the three padding entries behind it
+    p.part[b * FPART + FH2 + (t - 128)] = t == 128 ? (S.misc[0] + S.misc[1]) + (S.misc[2] + S.misc[3]) : 0.f;
+  }
+  // --- dH1 = dZ2 W2, dZ1 = dH1 where H1 > 0, in place over H1 ---
+  {
+    f4v acc[FFRAGS][2];
+#pragma unroll
+    for (int i = 0; i < FFRAGS; ++i) acc[i][0] = acc[i][1] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < FFRAGS; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const s8v fa = *reinterpret_cast<const s8v*>(S.z2 + img_off(i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, wb2[jj][kk]),
+                                                               __builtin_bit_cast(bf8v, fa), acc[i][jj], 0, 0, 0);
+      }
+#pragma unroll
+    for (int i = 0; i < FFRAGS; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int n0 = (2 * w + jj) * 16 + (lane >> 4) * 4, m = i * 16 + (lane & 15);
+        char* at = S.h1[n0 >> 6] + img_off(m, (n0 & 63) >> 3) + (n0 & 7) * 2;
+        const uint2 h = *reinterpret_cast<const uint2*>(at);
+        const f4v v = acc[i][jj];
+        uint2 z;
+        z.x = (uint32_t) (bfl(h.x) > 0.f ? mi_f2bf(v.x) : (unsigned short) 0) |
+              ((uint32_t) (bfh(h.x) > 0.f ? mi_f2bf(v.y) : (unsigned short) 0) << 16);
+        z.y = (uint32_t) (bfl(h.y) > 0.f ? mi_f2bf(v.z) : (unsigned short) 0) |
+              ((uint32_t) (bfh(h.y) > 0.f ? mi_f2bf(v.w) : (unsigned short) 0) << 16);
+        *reinterpret_cast<uint2*>(at) = z;
+      }
+  }
+  lds_barrier();  // dZ1 is complete
+  // --- dZ1 to HBM (whole rows contiguous) and its column sums over the sample's rows ---
+  {
+    float cs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cs[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < FFRAGS; ++s) {
+      const int r = r16 + 16 * s;
+      const uint4 z = *reinterpret_cast<const uint4*>(S.h1[c16 >> 3] + img_off(r, c16 & 7));
+      if (r < L) {
+        *reinterpret_cast<uint4*>(p.dZ1 + (row0 + r) * FH1 + c16 * 8) = z;
+        cs[0] += bfl(z.x); cs[1] += bfh(z.x); cs[2] += bfl(z.y); cs[3] += bfh(z.y);
+        cs[4] += bfl(z.z); cs[5] += bfh(z.z); cs[6] += bfl(z.w); cs[7] += bfh(z.w);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      cs[i] += __shfl_xor(cs[i], 16, 64);
+      cs[i] += __shfl_xor(cs[i], 32, 64);
+    }
+    // S.red was last read behind the barrier before last: free again
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) S.red[w][lane * 8 + i] = cs[i];
+    }
+  }
+  // --- [gk | gp] = dZ1 W1f: wave w owns columns [16 w, 16 w + 16) of both halves ---
+  f4v acc[FFRAGS][2];
+#pragma unroll
+  for (int i = 0; i < FFRAGS; ++i) acc[i][0] = acc[i][1] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < FFRAGS; ++i)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const s8v fa = *reinterpret_cast<const s8v*>(S.h1[kk >> 1] + img_off(i * 16 + (lane & 15), (kk & 1) * 4 + (lane >> 4)));
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, wb1[jj][kk]),
+                                                             __builtin_bit_cast(bf8v, fa), acc[i][jj], 0, 0, 0);
+    }
+  lds_barrier();  // dZ1 (and dZ2) have been read by everybody: their space takes d k and gp now
+  if (t < FH1) p.S[b * FH1 + t] = (S.red[0][t] + S.red[1][t]) + (S.red[2][t] + S.red[3][t]);
+  // d k = a_j dpooled + gk + q * gp on live positions (gk, gp rounded to bf16 as the separate launches store them):
+  // fp32 rows of FD floats, their 16-byte chunks XORed with the row so that a fragment's 16 rows spread over banks
+  {
+    float* dk = reinterpret_cast<float*>(S.h1[0]);
+#pragma unroll
+    for (int i = 0; i < FFRAGS; ++i) {
+      const int m = i * 16 + (lane & 15);
+      const f4v vk = acc[i][0], vp = acc[i][1];
+      const uint2 gpu = pack4(vp.x, vp.y, vp.z, vp.w);
+      const uint2 gku = pack4(vk.x, vk.y, vk.z, vk.w);
+      const float aw = S.a[m];
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (S.live[m]) {
+        o.x = fmaf(aw, dpd.x, fmaf(qd.x, bfl(gpu.x), bfl(gku.x)));
+        o.y = fmaf(aw, dpd.y, fmaf(qd.y, bfh(gpu.x), bfh(gku.x)));
+        o.z = fmaf(aw, dpd.z, fmaf(qd.z, bfl(gpu.y), bfl(gku.y)));
+        o.w = fmaf(aw, dpd.w, fmaf(qd.w, bfh(gpu.y), bfh(gku.y)));
+      }
+      *reinterpret_cast<float4*>(dk + m * FD + (((d0 >> 2) ^ (m & 15)) << 2)) = o;
+      *reinterpret_cast<uint2*>(S.z2 + img_off(m, d0 >> 3) + (d0 & 7) * 2) = gpu;
+    }
+  }
+  lds_barrier();
+  // --- d k rows to HBM; d q = dq_above + sum_j k_j * gp over the threads that still hold the k chunks ---
+#pragma unroll
+  for (int s = 0; s < FFRAGS; ++s) {
+    const int r = r16 + 16 * s;
+    if (r < L) {
+      const float* dk = reinterpret_cast<const float*>(S.h1[0]);
+      *reinterpret_cast<float4*>(p.dE + (b * (L + 1) + r) * FD + c16 * 4) =
+          *reinterpret_cast<const float4*>(dk + r * FD + ((c16 ^ (r & 15)) << 2));
+    }
+  }
+  {
+    float sq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sq[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int r = r8 + 32 * s;
+      if (r < FROWS) {
+        const uint4 g = *reinterpret_cast<const uint4*>(S.z2 + img_off(r, c8));
+        const uint4 k = kreg[s];  // zero on masked positions and behind the history
+        sq[0] = fmaf(bfl(k.x), bfl(g.x), sq[0]); sq[1] = fmaf(bfh(k.x), bfh(g.x), sq[1]);
+        sq[2] = fmaf(bfl(k.y), bfl(g.y), sq[2]); sq[3] = fmaf(bfh(k.y), bfh(g.y), sq[3]);
+        sq[4] = fmaf(bfl(k.z), bfl(g.z), sq[4]); sq[5] = fmaf(bfh(k.z), bfh(g.z), sq[5]);
+        sq[6] = fmaf(bfl(k.w), bfl(g.w), sq[6]); sq[7] = fmaf(bfh(k.w), bfh(g.w), sq[7]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) sq[i] += __shfl_xor(sq[i], o, 64);
+    if (lane < 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) S.red[w][lane * 8 + i] = sq[i];
+    }
+  }
+  lds_barrier();
+  if (t < FD)
+    p.dE[(b * (L + 1) + L) * FD + t] =
+        p.dfeat[b * p.ld_dfeat + FD + t] + ((S.red[0][t] + S.red[1][t]) + (S.red[2][t] + S.red[3][t]));
+}
+
+// out[s][c] = sum of in[r][c] over the rows of slice s (rows in ascending order): one thread per column
+__global__ __launch_bounds__(256) void rows_sum_f32_kernel(const float* __restrict__ in, int64_t R, int n, int rps,
+                                                          float* __restrict__ out) {
+  const int c = threadIdx.x;
+  if (c >= n) return;
+  const int64_t lo = (int64_t) blockIdx.x * rps;
+  const int64_t hi = lo + rps < R ? lo + rps : R;
+  float acc = 0.f;
+  int64_t r = lo;
+  for (; r + 8 <= hi; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = in[(r + j) * n + c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j];
+  }
+  for (; r < hi; ++r) acc += in[r * n + c];
+  out[(int64_t) blockIdx.x * n + c] = acc;
+}
+
 }  // namespace
 
 extern "C" int mi_din_lau_fwd_fused_ok(int dim, int h1, int h2, int L, int factored) {
@@ -366,6 +705,37 @@ extern "C" int mi_din_lau_fwd_fused(const float* E, int64_t rows, const void* hi
   const unsigned grid = (unsigned) B;
   if (idx_bits == 32) hipLaunchKernelGGL(din_lau_fwd_fused_kernel<int32_t>, dim3(grid), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(din_lau_fwd_fused_kernel<int64_t>, dim3(grid), dim3(256), 0, s, p);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_din_lau_bwd_part_floats(void) { return FPART; }
+
+extern "C" int mi_din_lau_bwd_fused(int64_t B, int L, const void* A, const void* H1, const void* H2, const float* a,
+                                    const int32_t* ids_all, const float* feat, int64_t ld_feat, const float* dfeat,
+                                    int64_t ld_dfeat, const float* w3, const void* W2T, const void* W1fT, void* dZ2,
+                                    void* dZ1, float* dE, float* S, float* part, int slices, float* part_sums,
+                                    void* stream) {
+  const char* who = "mi_din_lau_bwd_fused";
+  MI_REQUIRE(A && H1 && H2 && a && ids_all && feat && dfeat && w3 && W2T && W1fT && dZ2 && dZ1 && dE && S && part && part_sums,
+             "%s: null pointer", who);
+  MI_REQUIRE(B >= 1 && B < ((int64_t) 1 << 31) && L >= 1 && L <= FROWS && slices >= 1 && slices <= B,
+             "%s: bad B / L / slices (L <= %d)", who, FROWS);
+  MI_REQUIRE(ld_feat >= 2 * FD && ld_feat % 4 == 0 && ld_dfeat >= 2 * FD && ld_dfeat % 4 == 0, "%s: leading dimensions", who);
+  auto a16 = [](const void* p) { return ((uintptr_t) p & 15) == 0; };
+  MI_REQUIRE(a16(A) && a16(H1) && a16(H2) && a16(feat) && a16(dfeat) && a16(w3) && a16(W2T) && a16(W1fT) && a16(dZ2) &&
+                 a16(dZ1) && a16(dE),
+             "%s: misaligned buffer", who);
+  FusedBwdArgs p{B, L, (const unsigned short*) A, (const unsigned short*) H1, (const unsigned short*) H2, a, ids_all, feat,
+                 ld_feat, dfeat, ld_dfeat, w3, (const unsigned short*) W2T, (const unsigned short*) W1fT,
+                 (unsigned short*) dZ2, (unsigned short*) dZ1, dE, S, part};
+  hipStream_t s = (hipStream_t) stream;
+  hipLaunchKernelGGL(din_lau_bwd_fused_kernel<0>, dim3((unsigned) B), dim3(256), 0, s, p);
+  MI_LAUNCH_CHECK();
+  // the per-sample sums of the small parameters' gradients down to `slices` rows (samples in ascending order)
+  const int rps = (int) mi_cdiv(B, slices);
+  MI_REQUIRE(mi_cdiv(B, rps) == slices, "%s: %d slices do not divide %lld samples into equal runs", who, slices, (long long) B);
+  hipLaunchKernelGGL(rows_sum_f32_kernel, dim3((unsigned) slices), dim3(256), 0, s, part, B, FPART, rps, part_sums);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

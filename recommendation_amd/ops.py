@@ -792,6 +792,20 @@ def din_lau_fwd_fused(E, hist, qid, lengths, W1f, Wq, b1, W2, b2, w3, A, H1, H2,
               feat.stride(0), _p(rowbias), _p(err), _stream())
 
 
+def din_lau_bwd_part_floats():
+    return int(_lib.load().mi_din_lau_bwd_part_floats())
+
+
+def din_lau_bwd_fused(A, H1, H2, a, ids_all, feat, dfeat, w3, W2T, W1fT, dZ2, dZ1, dE, S, part, part_sums):
+    """The data path of the factored unit's backward in one launch per sample: dZ2, dZ1, dE (the candidate's row
+    still without its S Wq term), S and the partial sums of the head's / second bias' gradients."""
+    B, L1 = ids_all.shape
+    _need_cuda(A, H1, H2, a, ids_all, feat, dfeat, w3, W2T, W1fT, dZ2, dZ1, dE, S, part, part_sums)
+    _lib.call('mi_din_lau_bwd_fused', B, L1 - 1, _p(A), _p(H1), _p(H2), _p(a), _p(ids_all), _p(feat), feat.stride(0),
+              _p(dfeat), dfeat.stride(0), _p(w3), _p(W2T), _p(W1fT), _p(dZ2), _p(dZ1), _p(dE), _p(S), _p(part),
+              part_sums.shape[0], _p(part_sums), _stream())
+
+
 def din_lau_pool(A, a, ids_all, dim, pooled):
     B, L1 = ids_all.shape
     _lib.call('mi_din_lau_pool', _p(A), A.shape[1], _p(a), _p(ids_all), B, L1 - 1, dim, _p(pooled), pooled.stride(0),

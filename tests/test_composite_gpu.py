@@ -135,16 +135,33 @@ def test_din_unit_calls_equal_the_launch_by_launch_sequence_bitwise(dev, factore
     qid = torch.from_numpy(rng.integers(0, rows, size=(B,))).to(dev)
     lengths = torch.from_numpy(rng.integers(0, L + 1, size=(B,)).astype(np.int32)).to(dev)
     labels = torch.from_numpy((rng.random(B) < 0.5).astype(np.float32)).to(dev)
-    for step in range(2):
-        la = a.train_step(hist, qid, lengths, labels).clone()
-        lb = _din_step_launch_by_launch(b, hist, qid, lengths, labels).clone()
-        assert torch.equal(la, lb)
-        assert torch.equal(a.feat, b.feat) and torch.equal(a.dE, b_dE(b))
+    if not factored:
+        for step in range(2):
+            la = a.train_step(hist, qid, lengths, labels).clone()
+            lb = _din_step_launch_by_launch(b, hist, qid, lengths, labels).clone()
+            assert torch.equal(la, lb)
+            assert torch.equal(a.feat, b.feat) and torch.equal(a.dE, b_dE(b))
+        for name, p in a.dense_params().items():
+            _same(p, b.dense_params()[name])
+        assert torch.equal(a.E, b.E) and torch.equal(a.E_acc, b.E_acc)
+        return
+    # The factored unit runs as one launch per direction (mi_din_lau_fwd_fused / mi_din_lau_bwd_fused): its forward
+    # and the history rows of dE are bit-identical to the sequence; the sums over positions / samples (the small
+    # parameters' gradients, the candidate's row) are added in another order, so the first step's gradients are held
+    # to 1e-5 of their scale and the parameters after it to one Adam step of the disagreeing elements.
+    from errlog import held
+    la = a.train_step(hist, qid, lengths, labels).clone()
+    lb = _din_step_launch_by_launch(b, hist, qid, lengths, labels).clone()
+    assert torch.equal(la, lb) and torch.equal(a.feat, b.feat)
+    L1 = L + 1
+    assert torch.equal(a.dE.view(B, L1, D)[:, :L], b_dE(b).view(B, L1, D)[:, :L])
+    held("DIN composite vs sequence: candidate rows of dE", float((a.dE - b_dE(b)).abs().max()) / float(b_dE(b).abs().max()), 1e-5)
     for name, p in a.dense_params().items():
-        _same(p, b.dense_params()[name])
-    assert torch.equal(a.E, b.E) and torch.equal(a.E_acc, b.E_acc)
-    if factored:
-        assert torch.equal(a.W1f, b.W1f) and torch.equal(a.W1fT, b.W1fT) and torch.equal(a.Wq, b.Wq) and torch.equal(a.WqT, b.WqT)
+        q = b.dense_params()[name]
+        scale = float(q.grad.abs().max()) + 1e-30
+        held("DIN composite vs sequence: grad " + name, float((p.grad - q.grad).abs().max()) / scale, 1e-5)
+        held("DIN composite vs sequence: param " + name, float((p.w - q.w).abs().max()), 2.5 * a.lr)
+    held("DIN composite vs sequence: table", float((a.E - b.E).abs().max()), 2.5 * a.emb_lr)
 
 
 def b_dE(m):
@@ -299,3 +316,75 @@ def test_din_fused_forward_equals_the_separate_launches_bitwise(dev, B, L, idx):
     for name in ('ids_all', 'err', 'A', 'H1', 'H2', 'a', 'feat'):
         assert torch.equal(x[name], y[name]), name
     assert int(x['err'][0]) != 0
+
+
+@pytest.mark.parametrize("B,L", [(64, 10), (32, 100), (8, 112), (8, 1)])
+def test_din_fused_backward_equals_the_separate_launches(dev, B, L):
+    """mi_din_lau_bwd_fused against mi_din_lau_pool_bwd + mi_head_bwd + the two masked mi_gemm_bf16 +
+    mi_din_lau_scatter_fact on the forward of the same batch: dZ2, dZ1 and the history rows of dE bit for bit; the
+    sums (S, the head's and the second bias' gradient, the candidate's row) are added in another order: 1e-5 of their
+    scale."""
+    from recommendation_amd import ops
+    rows, D, H, H2 = 3000, 64, 128, 64
+    g = torch.Generator(device='cpu').manual_seed(23 + L)
+    f32 = dict(dtype=torch.float32, device=dev)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+
+    def rnd(*shape, scale=0.1):
+        return (torch.randn(shape, generator=g) * scale).to(dev)
+    E = rnd(rows, D, scale=0.3)
+    W1f, Wq, b1 = rnd(H, 2 * D).to(torch.bfloat16), rnd(H, D), rnd(H)
+    W2, b2 = rnd(H2, H).to(torch.bfloat16), rnd(H2)
+    w3 = torch.zeros((H2 + 4,), **f32)
+    w3[:H2 + 1] = rnd(H2 + 1, scale=0.2)
+    W2T, W1fT = W2.t().contiguous(), W1f.t().contiguous()
+    hist = torch.randint(0, rows, (B, L), generator=g)
+    hist[0, 0] = -1
+    qid = torch.randint(0, rows, (B,), generator=g)
+    lengths = torch.randint(0, L + 1, (B,), generator=g).to(torch.int32)
+    lengths[0] = L
+    lengths[1] = 0
+    hist, qid, lengths = hist.to(dev), qid.to(dev), lengths.to(dev)
+    M = B * L
+    A, H1t, H2t = torch.empty((M, 2 * D), **bf), torch.empty((M, H), **bf), torch.empty((M, H2), **bf)
+    a, ids_all = torch.empty((M,), **f32), torch.empty((B, L + 1), dtype=torch.int32, device=dev)
+    feat = torch.empty((B, 2 * D), **f32)
+    ops.din_lau_fwd_fused(E, hist, qid, lengths, W1f, Wq, b1, W2, b2, w3, A, H1t, H2t, a, ids_all, feat,
+                          torch.empty((B, H), **f32))
+    dfeat = rnd(B, 2 * D, scale=1.0)
+    # fused
+    P = ops.din_lau_bwd_part_floats()
+    slices = 8 if B % 8 == 0 else 1
+    x = dict(dZ2=torch.full((M, H2), 7.0, **bf), dZ1=torch.full((M, H), 7.0, **bf), dE=torch.full((B * (L + 1), D), 7.0, **f32),
+             S=torch.empty((B, H), **f32), part=torch.empty((B, P), **f32), sums=torch.empty((slices, P), **f32))
+    ops.din_lau_bwd_fused(A, H1t, H2t, a, ids_all, feat, dfeat, w3, W2T, W1fT, x['dZ2'], x['dZ1'], x['dE'], x['S'],
+                          x['part'], x['sums'])
+    # separate launches
+    da, dA = torch.empty((M,), **f32), torch.empty((M, 2 * D), **bf)
+    y = dict(dZ2=torch.empty((M, H2), **bf), dZ1=torch.empty((M, H), **bf), dE=torch.empty((B * (L + 1), D), **f32),
+             S=torch.empty((B, H), **f32))
+    vs = max(1, min(1024, M // 64))
+    part = torch.zeros((vs, H2 + 4), **f32)
+    ops.din_lau_pool_bwd(A, dfeat, ids_all, D, da)
+    ops.head_bwd(da, w3[:H2], H2t, y['dZ2'], vs, part)
+    ops.gemm_bf16(y['dZ2'], W2T, ops.MI_EPI_MASK, out=y['dZ1'], in0=H1t)
+    ops.colsum_bf16(y['dZ1'], B, y['S'], N=H)
+    ops.gemm_bf16(y['dZ1'], W1fT, ops.MI_EPI_MASK, out=dA)
+    ops.din_lau_scatter_fact(A, dA, a, dfeat, dfeat[:, D:], feat[:, D:], ids_all, D, y['dE'])
+    b2part = torch.empty((vs, H2), **f32)
+    ops.colsum_bf16(y['dZ2'], vs, b2part, N=H2)
+    torch.cuda.synchronize()
+    assert torch.equal(x['dZ2'], y['dZ2']) and torch.equal(x['dZ1'], y['dZ1'])
+    xe, ye = x['dE'].view(B, L + 1, D), y['dE'].view(B, L + 1, D)
+    assert torch.equal(xe[:, :L], ye[:, :L])
+
+    def close(u, v, what):
+        scale = float(v.abs().max()) + 1e-30
+        err = float((u - v).abs().max()) / scale
+        from errlog import held
+        held("DIN fused backward B=%d L=%d %s" % (B, L, what), err, 1e-5)
+    close(xe[:, L], ye[:, L], "candidate row")
+    close(x['S'], y['S'], "S")
+    close(x['sums'][:, :H2 + 1].sum(0), part[:, :H2 + 1].sum(0), "head gradient")
+    close(x['sums'][:, H2 + 4:].sum(0), b2part.sum(0), "b2 gradient")
+    assert float(x['sums'][:, H2 + 1:H2 + 4].abs().max()) == 0.0
