@@ -849,23 +849,42 @@ def bench_din(args):
                      hidden_padded=[m.h1p, m.h2p], accumulate='f32',
                      optimizer='adam_tf (dense) + adagrad_rowwise (table)'))
     res['step_tflops'] = round(m.flops_per_sample() * B * args.steps / dt / 1e12, 1)
-    # dominant HBM kernel: the gather that builds the unit's input rows
-    ms = time_rotating(lambda j: ops.din_lau_build(m.E, batches[j][0], batches[j][1], batches[j][2], m.A, m.ids_all,
-                                                   q_out=m.feat[:, 64:], err=m.err), len(batches), args.stage_reps)
-    live = sum(int(b[2].sum().item()) for b in batches) / float(len(batches))
     ib = args.idx_bits // 8
-    nbytes = live * 64 * 4 + B * L * ib + B * L * m.A.shape[1] * 2 + B * (L + 1) * 4   # live rows + ids + A rows + index list
     res['config']['first_layer'] = 'factored: rows [k | q*k], q term per sample' if m.factored else 'full rows [q | k | q-k | q*k]'
-    res['roofline'] = {'kernel': 'din_build_kernel (gather + %s rows)' % ('[k|q*k]' if m.factored else '[q|k|q-k|q*k]'),
-                       'bound': 'hbm',
-                       'achieved': round(nbytes / ms / 1e6, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                       'frac': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
-                       # the committed counter passes ran the factored form (the default)
-                       'traffic': ((_pmc_traffic('r03_din_b8192_pmc.json', res['config']['workload'], 'din_build_kernel') or
-                                    _pmc_traffic('r02_din_b8192_pmc.json', res['config']['workload'], 'din_build_kernel'))
-                                   if m.factored else None),
-                       'traffic_source': 'quoted profiles/r0x_din_b8192_pmc.json (null when absent or another workload)',
-                       'alg_bytes_per_launch': nbytes, 'ms_per_launch': round(ms, 5)}
+    D, H, H2 = 64, m.h1p, m.h2p
+    if m.factored and ops.din_lau_fwd_fused_ok(D, H, H2, L):
+        # The unit runs as one launch per direction; the dominant HBM kernel is the backward's data path.  It reads the
+        # k block of A, H1, H2 and the weights a, writes dZ2, dZ1 and the rows' gradient: B*L rows whatever the lengths.
+        res['config']['unit'] = 'one launch per direction, a workgroup per sample (layers out of LDS)'
+        W2T, W1fT = m.W2.hT, m.W1fT
+        dfeat = torch.randn((B, 2 * D), device=dev)
+        P = ops.din_lau_bwd_part_floats()
+        S_, part, sums = (torch.empty((B, H), device=dev), torch.empty((B, P), device=dev), torch.empty((256, P), device=dev))
+        dZ2, dZ1, dE = torch.empty_like(m.H2), torch.empty_like(m.H1), torch.empty((B * (L + 1), D), device=dev)
+        m.train_step(*batches[0])
+        ms = time_rotating(lambda j: ops.din_lau_bwd_fused(m.A, m.H1, m.H2, m.a, m.ids_all, m.feat, dfeat, m.w3.w, W2T, W1fT,
+                                                           dZ2, dZ1, dE, S_, part, sums), 1, args.stage_reps)
+        nbytes = B * L * (D * 2 + H * 2 + H2 * 2 + 4 + 4) + B * L * (H2 * 2 + H * 2) + B * (L + 1) * D * 4 + B * (H + P) * 4
+        res['roofline'] = {'kernel': 'din_lau_bwd_fused_kernel (+ rows_sum_f32_kernel, 3 us): reads k, H1, H2, a; writes dZ2, dZ1, dE',
+                           'bound': 'hbm',
+                           'achieved': round(nbytes / ms / 1e6, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                           'traffic': _pmc_traffic('r03_din_b8192_pmc.json', res['config']['workload'], 'din_lau_bwd_fused_kernel'),
+                           'traffic_source': 'quoted profiles/r03_din_b8192_pmc.json (null when absent or another workload)',
+                           'alg_bytes_per_launch': nbytes, 'ms_per_launch': round(ms, 5)}
+    else:
+        # dominant HBM kernel: the gather that builds the unit's input rows
+        ms = time_rotating(lambda j: ops.din_lau_build(m.E, batches[j][0], batches[j][1], batches[j][2], m.A, m.ids_all,
+                                                       q_out=m.feat[:, 64:], err=m.err), len(batches), args.stage_reps)
+        live = sum(int(b[2].sum().item()) for b in batches) / float(len(batches))
+        nbytes = live * 64 * 4 + B * L * ib + B * L * m.A.shape[1] * 2 + B * (L + 1) * 4   # live rows + ids + A rows + index list
+        res['roofline'] = {'kernel': 'din_build_kernel (gather + %s rows)' % ('[k|q*k]' if m.factored else '[q|k|q-k|q*k]'),
+                           'bound': 'hbm',
+                           'achieved': round(nbytes / ms / 1e6, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                           'traffic': None,
+                           'traffic_source': None,
+                           'alg_bytes_per_launch': nbytes, 'ms_per_launch': round(ms, 5)}
     if not args.no_cpu_baseline:
         from oracle import din as odin
         Bc = 1024

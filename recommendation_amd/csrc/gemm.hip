@@ -28,9 +28,6 @@ typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s4v* lds_s4v_ptr;
 
-#ifndef GEMM_PIPE
-#define GEMM_PIPE 1
-#endif
 constexpr int BK = 64;
 constexpr int SUB_BYTES = 128 * BK * 2;  // an operand tile is made of 128-row sub-tiles of 16 KiB
 
@@ -376,7 +373,7 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) void gemm_bf16_k
     stb.stage(k0_, Bs + (buf_) * B_BYTES, w);                        \
   } while (0)
 
-#if GEMM_PIPE
+  if constexpr (NWAVES == 8) {  // one workgroup per CU: nothing else covers a bubble at the tile boundary
   // The K loop as ONE stream of MFMA rows (a row = one A fragment against the FN resident B
   // fragments) that runs across tile boundaries.  An A fragment is read RING rows before the MFMAs
   // that use it; the barrier that hands over the next tile sits RING rows before the end of a tile,
@@ -469,7 +466,7 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) void gemm_bf16_k
     if (kt + 1 < ktiles) tile(kt++, std::true_type{}, std::false_type{});
     if (kt < ktiles) tile(kt, std::false_type{}, std::false_type{});
   }
-#else
+  } else {  // two workgroups per CU cover each other; the tile-by-tile loop needs fewer registers
 #pragma unroll
   for (int s = 0; s < D; ++s)
     if (s < ktiles) STAGE(s, s);
@@ -530,7 +527,7 @@ __global__ __launch_bounds__(WM* WN * 64, WM * WN == 4 ? 2 : 1) void gemm_bf16_k
     }
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
-#endif
+  }
 #undef STAGE
   // Epilogue.  In the accumulators a lane holds 4 consecutive n of ONE row m, and the 16 lanes of a
   // group hold 16 different rows: stored like that, every instruction touches 16 rows with 32 bytes
