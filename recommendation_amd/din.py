@@ -75,6 +75,8 @@ class DIN(object):
         self.err = ops.new_error_word(self.device)
         self.steps = 0
         self._B = None
+        self.overlap_sort = True   # the id sort beside the backward, on a side stream (train_step)
+        self._side = None
         if self.factored:
             self._derive_w1()
 
@@ -147,6 +149,15 @@ class DIN(object):
         self.plan = ops.SortedPlan(self.toffs, 1, self.rows, self.ids_all.view(-1), bag_len=1, runs=False)
         self._B = (B, hist.dtype)
 
+    def _side_stream(self):
+        """The stream the id sort runs on beside the backward (None: sort in line, e.g. under graph capture)."""
+        if not self.overlap_sort or torch.cuda.is_current_stream_capturing():
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+            self._ev_ids, self._ev_sorted = torch.cuda.Event(), torch.cuda.Event()
+        return self._side
+
     # -- forward ------------------------------------------------------------------------------
     def forward(self, hist, qid, lengths, labels=None):
         """hist [B, L] ids, qid [B] ids, lengths [B] int32 -> logits [B]; pooled interest vectors in
@@ -168,6 +179,17 @@ class DIN(object):
         B = hist.shape[0]
         D = self.dim
         self.forward(hist, qid, lengths, labels)
+        # The sort of the step's row ids needs nothing but ids_all, which the forward has just written: it runs on
+        # a side stream beside the output layer and the unit's backward (nine small launches that leave most of
+        # the chip idle) and is joined in front of the table update.
+        side = self._side_stream()
+        if side is not None:
+            main = torch.cuda.current_stream()
+            self._ev_ids.record(main)
+            side.wait_event(self._ev_ids)
+            with torch.cuda.stream(side):
+                self.plan.prepare(self.ids_all.view(-1))
+                self._ev_sorted.record(side)
         ops.reduce_sum(self.loss_rows, 1.0 / B, out=self.loss)
         ops.adam_schedule_step(self.sched, self.lr, self.beta1, self.beta2)
         # output layer
@@ -179,7 +201,10 @@ class DIN(object):
         # the unit, output side first: data gradients with the weights the forward saw, every weight step, and the
         # per-position gradients of the gathered rows
         self.unit.backward(self.feat, dfeat, self.ids_all, self.dE, self.beta1, self.beta2, self.eps, lr_dev=self.sched)
-        self.plan.prepare(self.ids_all.view(-1))
+        if side is not None:
+            torch.cuda.current_stream().wait_event(self._ev_sorted)
+        else:
+            self.plan.prepare(self.ids_all.view(-1))
         ops.bwd_apply_adagrad_rowwise(self.plan, self.dE, self.E, self.E_acc, self.emb_lr, self.emb_eps, grad_ld=D)
         self.steps += 1
         if check_ids:
