@@ -104,6 +104,36 @@ __global__ __launch_bounds__(256) void linear_dw_final_kernel(const float* __res
   else if (db) db[e - K * N] = acc;
 }
 
+// The same under many slices (a batch of thousands of rows): 16 lanes share an element's slices - lane l adds
+// slices l, l + 16, ... in order, eight loads in flight - and the 16 partial sums are added in lane order.
+__global__ __launch_bounds__(256) void linear_dw_final_wide_kernel(const float* __restrict__ partial, int splits, int K,
+                                                                  int N, float* __restrict__ dW, float* __restrict__ db) {
+  const int total = K * N + N;
+  const int lane = threadIdx.x & 15;
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = e < total;
+  float acc = 0.f;
+  if (live) {
+    for (int s0 = lane; s0 < splits; s0 += 16 * 8) {
+      float p[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int s = s0 + 16 * j;
+        p[j] = s < splits ? partial[(int64_t) s * total + e] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += p[j];
+    }
+  }
+  // lanes 0..15 of a group in lane order: ((l0 + l1) + l2) + ...
+  float sum = __shfl(acc, (threadIdx.x & 48) | 0, 64);
+#pragma unroll
+  for (int l = 1; l < 16; ++l) sum += __shfl(acc, (threadIdx.x & 48) | l, 64);
+  if (!live || lane != 0) return;
+  if (e < K * N) dW[e] = sum;
+  else if (db) db[e - K * N] = sum;
+}
+
 // one wave per row
 __global__ __launch_bounds__(256) void softmax_heads_kernel(const float* __restrict__ logits, int64_t ld, int64_t B,
                                                            int N, int k, const float* __restrict__ labels,
@@ -283,8 +313,12 @@ extern "C" int mi_linear_bwd(const float* x, int64_t x_ld, const float* W, const
   const unsigned dx_blocks = dx ? (unsigned) mi_cdiv(B * K, 256) : 0u;
   hipLaunchKernelGGL(linear_bwd_kernel, dim3((unsigned) splits + dx_blocks), dim3(256), 0, s, x, x_ld, W, dy, dy_ld, dx,
                      dx_ld, (float*) workspace, B, K, N, splits, ROWS_PER_SPLIT);
-  hipLaunchKernelGGL(linear_dw_final_kernel, dim3((unsigned) mi_cdiv(K * N + N, 256)), dim3(256), 0, s,
-                     (const float*) workspace, splits, K, N, dW, db);
+  if (splits >= 64)  // a walk over that many slices by one thread is a chain of splits / 8 round trips
+    hipLaunchKernelGGL(linear_dw_final_wide_kernel, dim3((unsigned) mi_cdiv(K * N + N, 16)), dim3(256), 0, s,
+                       (const float*) workspace, splits, K, N, dW, db);
+  else
+    hipLaunchKernelGGL(linear_dw_final_kernel, dim3((unsigned) mi_cdiv(K * N + N, 256)), dim3(256), 0, s,
+                       (const float*) workspace, splits, K, N, dW, db);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
