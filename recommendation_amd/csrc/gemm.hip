@@ -626,7 +626,11 @@ int dispatch_gemm(GemmArgs& g, int splits, hipStream_t s) {
   // transposing reads and 241 VGPRs lose, and narrow outputs do not fill its 256 columns.
   const int64_t big = mi_cdiv(g.M, 256) * mi_cdiv(g.N, 256) * splits;
   const bool fills = mi_cdiv(g.N, 256) * 256 * 100 <= g.N * 115;  // at most 15 % of the columns are padding
-  if (!A_TR && big >= 128 && fills && (!B_TR || g.N >= 512)) return launch_gemm<A_TR, B_TR, 2, 4, 8, 4, 2>(g, splits, s);
+  // ... and the cross layer's forward epilogue (two input and two output tensors per tile, five 58.7 MB tensors a
+  // launch at width 448) runs better under two workgroups per CU, whose epilogues overlap the other's K loop:
+  // 54 / 70 / 65 us with the big tile, 48 / 57 / 57 us with the small one for the three layers at batch 65536
+  const bool heavy_epilogue = g.e.mode == MI_EPI_CROSS_FWD;
+  if (!heavy_epilogue && !A_TR && big >= 128 && fills && (!B_TR || g.N >= 512)) return launch_gemm<A_TR, B_TR, 2, 4, 8, 4, 2>(g, splits, s);
   return launch_gemm<A_TR, B_TR, 2, 2, 4, 4, 2>(g, splits, s);
 }
 
