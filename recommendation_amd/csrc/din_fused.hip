@@ -418,8 +418,6 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
     for (int kk = 0; kk < 2; ++kk)
       wb2[jj][kk] = *reinterpret_cast<const s8v*>(p.W2T + ((2 * w + jj) * 16 + (lane & 15)) * FH2 + kk * 32 + 8 * (lane >> 4));
   const int d0 = w * 16 + (lane >> 4) * 4;  // the lane's four columns of d k
-  const float4 dpd = *reinterpret_cast<const float4*>(p.dfeat + b * p.ld_dfeat + d0);
-  const float4 qd = *reinterpret_cast<const float4*>(p.feat + b * p.ld_feat + FD + d0);
 
   // --- da_j = <dpooled, k_j>: four columns at a time, then the tree of the separate kernel (its 16 lanes of 4
   // columns are this kernel's 8 lanes of 2 x 4) ---
@@ -446,12 +444,6 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
   for (int s = 0; s < FFRAGS; ++s)
     *reinterpret_cast<uint4*>(S.h1[c16 >> 3] + img_off(r16 + 16 * s, c16 & 7)) = h1reg[s];
   lds_barrier();
-  // (requested now that the registers of the H1 chunks are free; needed two phases further on)
-#pragma unroll
-  for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      wb1[jj][kk] = *reinterpret_cast<const s8v*>(p.W1fT + ((w + 4 * jj) * 16 + (lane & 15)) * FH1 + kk * 32 + 8 * (lane >> 4));
   // --- dZ2 = da_j w3 where H2 > 0: by the threads that hold the H2 chunks, straight to HBM and into the operand
   // image; the same pass leaves the thread's share of the sums over the sample's rows ---
   float sw3[8], sb2[8], sda = 0.f;
@@ -503,6 +495,13 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
     if (lane == 0) S.misc[w] = sda;
   }
   lds_barrier();  // dZ2 image and the partial sums are there
+  // (the last layer's fragments, requested now that the registers of the H1 / H2 chunks and of the sums are free;
+  // needed two phases further on)
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      wb1[jj][kk] = *reinterpret_cast<const s8v*>(p.W1fT + ((w + 4 * jj) * 16 + (lane & 15)) * FH1 + kk * 32 + 8 * (lane >> 4));
   if (t < 128) {
     const float v = (S.red[0][t] + S.red[1][t]) + (S.red[2][t] + S.red[3][t]);
     p.part[b * FPART + (t < 64 ? t : t + 4)] = v;
@@ -568,6 +567,10 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
     }
   }
   // --- [gk | gp] = dZ1 W1f: wave w owns columns [16 w, 16 w + 16) of both halves ---
+  // (dpooled and q of the lane's columns are requested here: used behind the products, and eight registers fewer
+  // through the phases above)
+  const float4 dpd = *reinterpret_cast<const float4*>(p.dfeat + b * p.ld_dfeat + d0);
+  const float4 qd = *reinterpret_cast<const float4*>(p.feat + b * p.ld_feat + FD + d0);
   f4v acc[FFRAGS][2];
 #pragma unroll
   for (int i = 0; i < FFRAGS; ++i) acc[i][0] = acc[i][1] = f4v{0.f, 0.f, 0.f, 0.f};
