@@ -59,7 +59,7 @@ struct FusedLds {
 
 #ifdef DIN_TRACE
 static __device__ unsigned long long din_trace_buf[64 * 16];
-#define DIN_MARK(k) do { if (t == 0 && it < 4 && blockIdx.x < 16) din_trace_buf[blockIdx.x * 64 + it * 16 + (k)] = wall_clock64(); } while (0)
+#define DIN_MARK(k) do { if (t == 0 && it < 4 && (blockIdx.x & ~15u) == 4096u) din_trace_buf[(blockIdx.x & 15) * 64 + it * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define DIN_MARK(k) do { } while (0)
 #endif
@@ -382,6 +382,9 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
   const int L = p.L;
   const int64_t b = blockIdx.x;
   const int64_t row0 = b * L;
+  const int it = 1;  // (trace slot of the backward)
+  (void) it;
+  DIN_MARK(0);
   // --- everything the sample needs from HBM, requested at once: 16-byte chunks, whole rows contiguous ---
   // k block and H2: chunk c8 = t & 7 (8 columns) of rows (t >> 3) + 32 s;  H1: chunk c16 = t & 15 of rows (t >> 4) + 16 s
   const int c8 = t & 7, r8 = t >> 3, c16 = t & 15, r16 = t >> 4;
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
       wb2[jj][kk] = *reinterpret_cast<const s8v*>(p.W2T + ((2 * w + jj) * 16 + (lane & 15)) * FH2 + kk * 32 + 8 * (lane >> 4));
   const int d0 = w * 16 + (lane >> 4) * 4;  // the lane's four columns of d k
 
+  DIN_MARK(1);
   // --- da_j = <dpooled, k_j>: four columns at a time, then the tree of the separate kernel (its 16 lanes of 4
   // columns are this kernel's 8 lanes of 2 x 4) ---
 #pragma unroll
@@ -444,6 +448,7 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
   for (int s = 0; s < FFRAGS; ++s)
     *reinterpret_cast<uint4*>(S.h1[c16 >> 3] + img_off(r16 + 16 * s, c16 & 7)) = h1reg[s];
   lds_barrier();
+  DIN_MARK(2);
   // --- dZ2 = da_j w3 where H2 > 0: by the threads that hold the H2 chunks, straight to HBM and into the operand
   // image; the same pass leaves the thread's share of the sums over the sample's rows ---
   float sw3[8], sb2[8], sda = 0.f;
@@ -494,6 +499,7 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
     }
     if (lane == 0) S.misc[w] = sda;
   }
+  DIN_MARK(3);
   lds_barrier();  // dZ2 image and the partial sums are there
   // (the last layer's fragments, requested now that the registers of the H1 / H2 chunks and of the sums are free;
   // needed two phases further on)
@@ -508,6 +514,7 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
   } else if (t < 132) {  // the head's bias gradient (sum of da) and the three padding entries behind it
     p.part[b * FPART + FH2 + (t - 128)] = t == 128 ? (S.misc[0] + S.misc[1]) + (S.misc[2] + S.misc[3]) : 0.f;
   }
+  DIN_MARK(4);
   // --- dH1 = dZ2 W2, dZ1 = dH1 where H1 > 0, in place over H1 ---
   {
     f4v acc[FFRAGS][2];
@@ -539,6 +546,7 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
         *reinterpret_cast<uint2*>(at) = z;
       }
   }
+  DIN_MARK(5);
   lds_barrier();  // dZ1 is complete
   // --- dZ1 to HBM (whole rows contiguous) and its column sums over the sample's rows ---
   {
@@ -566,6 +574,7 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
       for (int i = 0; i < 8; ++i) S.red[w][lane * 8 + i] = cs[i];
     }
   }
+  DIN_MARK(6);
   // --- [gk | gp] = dZ1 W1f: wave w owns columns [16 w, 16 w + 16) of both halves ---
   // (dpooled and q of the lane's columns are requested here: used behind the products, and eight registers fewer
   // through the phases above)
@@ -584,6 +593,7 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
         acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, wb1[jj][kk]),
                                                              __builtin_bit_cast(bf8v, fa), acc[i][jj], 0, 0, 0);
     }
+  DIN_MARK(7);
   lds_barrier();  // dZ1 (and dZ2) have been read by everybody: their space takes d k and gp now
   if (t < FH1) p.S[b * FH1 + t] = (S.red[0][t] + S.red[1][t]) + (S.red[2][t] + S.red[3][t]);
   // d k = a_j dpooled + gk + q * gp on live positions (gk, gp rounded to bf16 as the separate launches store them):
@@ -609,6 +619,7 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
     }
   }
   lds_barrier();
+  DIN_MARK(8);
   // --- d k rows to HBM; d q = dq_above + sum_j k_j * gp over the threads that still hold the k chunks ---
 #pragma unroll
   for (int s = 0; s < FFRAGS; ++s) {
@@ -645,6 +656,7 @@ __global__ __launch_bounds__(256, 3) void din_lau_bwd_fused_kernel(FusedBwdArgs 
     }
   }
   lds_barrier();
+  DIN_MARK(9);
   if (t < FD)
     p.dE[(b * (L + 1) + L) * FD + t] =
         p.dfeat[b * p.ld_dfeat + FD + t] + ((S.red[0][t] + S.red[1][t]) + (S.red[2][t] + S.red[3][t]));

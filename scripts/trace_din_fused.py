@@ -24,8 +24,11 @@ lib = _lib.load()
 lib.mi_debug_din_trace.argtypes = [ctypes.c_void_p]
 assert lib.mi_debug_din_trace(buf) == 0
 a = np.array(buf, dtype=np.uint64).reshape(16, 4, 16).astype(np.float64) / 100.0  # 100 MHz -> us
-names = ['top', 'tile built', 'barrier+prefetch issued', 'A copied', 'layer1 done', 'barrier', 'epi1+barrier', 'H1 copied', 'layer2', '...', 'end']
-for wg in (0, 5):
-    for it in range(4):
-        r = a[wg, it]
-        print("wg %d it %d: " % (wg, it) + " ".join("%.2f" % (r[k] - r[0]) for k in range(11)) + "  | since kernel start %.2f" % (r[0] - a[:, 0, 0].min()))
+for wg in (0, 5, 11):
+    r = a[wg, 0]
+    print("fwd wg %d: " % wg + " ".join("%.2f" % (r[k] - r[0]) for k in range(11)))
+for wg in (0, 5, 11):
+    r = a[wg, 1]
+    print("bwd wg %d: " % wg + " ".join("%.2f" % (r[k] - r[0]) for k in range(10)))
+print("bwd marks: 0 start | 1 loads issued | 2 da + H1 in LDS + barrier | 3 dZ2 + sums | 4 barrier, part out | 5 dH1 + mask |"
+      " 6 barrier + dZ1 out + S | 7 dA products | 8 barrier + dk staging + barrier | 9 dE out + dq reduce + barrier")
