@@ -238,6 +238,8 @@ __global__ __launch_bounds__(256) void din_qterm_fwd_kernel(const float* __restr
                                                            int64_t B, int H, float* __restrict__ out) {
   constexpr int D = 64;
   __shared__ float w[128][D + 1];
+  // (eight loads requested before the first is stored: a plain loop is a chain of H*D/256 memory round trips)
+#pragma unroll 8
   for (int i = threadIdx.x; i < H * D; i += 256) w[i / D][i % D] = Wq[i];
   __syncthreads();
   const int per = H / 4;  // threads per sample
@@ -275,16 +277,23 @@ __global__ __launch_bounds__(256) void din_qterm_bwd_kernel(const float* __restr
   __shared__ float sq[QB_CHUNK][D];
   __shared__ float sS[QB_CHUNK][128];
   __shared__ float sW[128][D];
+  // (staging loops unrolled so that eight loads are requested before the first is stored: as plain loops they are
+  // chains of 32 + 8 + 16 memory round trips; rows past the batch re-read row b0 and are zeroed)
+#pragma unroll 8
   for (int i = threadIdx.x; i < H * D; i += 256) sW[i / D][i % D] = Wq[i];
   const int64_t b0 = (int64_t) blockIdx.x * QB_CHUNK;
   const int nb = (int) (B - b0 < QB_CHUNK ? B - b0 : QB_CHUNK);
+#pragma unroll 8
   for (int i = threadIdx.x; i < QB_CHUNK * D; i += 256) {
     const int r = i / D, c = i % D;
-    sq[r][c] = r < nb ? q[(b0 + r) * ld_q + c] : 0.f;
+    const float v = q[(b0 + (r < nb ? r : 0)) * ld_q + c];
+    sq[r][c] = r < nb ? v : 0.f;
   }
+#pragma unroll 8
   for (int i = threadIdx.x; i < QB_CHUNK * H; i += 256) {
     const int r = i / H, c = i % H;
-    sS[r][c] = r < nb ? S[(b0 + r) * H + c] : 0.f;
+    const float v = S[(b0 + (r < nb ? r : 0)) * H + c];
+    sS[r][c] = r < nb ? v : 0.f;
   }
   __syncthreads();
   // dq: TPS threads per sample, CPT columns j each
