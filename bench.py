@@ -1118,9 +1118,12 @@ def main():
     # device idles between two graph launches are then paid once per replay, not once per step
     nb = len(batches)
     multi = use_graph and not prefetch_sort and not args.single_step_graphs and B <= model._fused_max and args.steps >= nb
+    rem = args.steps % nb if multi else 0      # a step count that is no multiple of nb ends with ONE shorter replay
     if multi:
         for _ in range(2):
             model.train_steps(batches, ids_tms=tms)
+            if rem > 1:
+                model.train_steps(batches[:rem], ids_tms=tms[:rem] if tms else None)   # (captured before timing)
     barrier()
     t0 = time.perf_counter()
     i = 0
@@ -1128,6 +1131,10 @@ def main():
         if multi and i % nb == 0 and i + nb <= args.steps:
             model.train_steps(batches, ids_tms=tms)       # steps i .. i + nb - 1
             i += nb
+            continue
+        if multi and rem > 1 and i % nb == 0 and i + rem == args.steps:
+            model.train_steps(batches[:rem], ids_tms=tms[:rem] if tms else None)   # the last `rem` steps
+            i += rem
             continue
         kw = kws[i % nb]
         if sharded and args.comm != 'rccl' and (args.prefetch or (world > 1 and not args.no_prefetch)):   # next batch's ids routed and exchanged beside this step's update
