@@ -63,8 +63,10 @@ def parse_args():
                     help='single-GPU step: sort the next batch\'s ids on a side stream beside this step instead of inside '
                          'the next one (bit-identical; measured slower at B = 8192: the stream hops and the third launch '
                          'cost more than the sort they hide)')
+    ap.add_argument('--steps-per-graph', type=int, default=32,
+                    help='fm workload: consecutive steps captured in one HIP graph (rounded down to whole rounds of the 8 resident batches)')
     ap.add_argument('--single-step-graphs', action='store_true',
-                    help='single-GPU step: one graph replay per step (default: one replay per 8 consecutive steps)')
+                    help='single-GPU step: one graph replay per step (default: one replay per --steps-per-graph consecutive steps)')
     ap.add_argument('--ids-sample-major', action='store_true',
                     help='feed the single-GPU step ids as [B][T] only (default: also one [B] row per field)')
     ap.add_argument('--force-sharded', action='store_true',
@@ -1118,22 +1120,30 @@ def main():
     # device idles between two graph launches are then paid once per replay, not once per step
     nb = len(batches)
     multi = use_graph and not prefetch_sort and not args.single_step_graphs and B <= model._fused_max and args.steps >= nb
-    rem = args.steps % nb if multi else 0      # a step count that is no multiple of nb ends with ONE shorter replay
+    # steps per replay: the resident batches in turn, round after round (a whole number of rounds, so that every
+    # replay starts at batch 0 - or the whole run when it is that short); a step count that is no multiple of it
+    # ends with ONE shorter replay
+    spg = (args.steps if args.steps <= args.steps_per_graph else max(nb, args.steps_per_graph // nb * nb)) if multi else 0
+    rem = args.steps % spg if multi else 0
+
+    def cycle(n):
+        return [batches[j % nb] for j in range(n)], ([tms[j % nb] for j in range(n)] if tms else None)
     if multi:
-        for _ in range(2):
-            model.train_steps(batches, ids_tms=tms)
+        full, rest = cycle(spg), cycle(rem)
+        for _ in range(2):                         # (captured before timing)
+            model.train_steps(full[0], ids_tms=full[1])
             if rem > 1:
-                model.train_steps(batches[:rem], ids_tms=tms[:rem] if tms else None)   # (captured before timing)
+                model.train_steps(rest[0], ids_tms=rest[1])
     barrier()
     t0 = time.perf_counter()
     i = 0
     while i < args.steps:
-        if multi and i % nb == 0 and i + nb <= args.steps:
-            model.train_steps(batches, ids_tms=tms)       # steps i .. i + nb - 1
-            i += nb
+        if multi and i % nb == 0 and i + spg <= args.steps:
+            model.train_steps(full[0], ids_tms=full[1])       # steps i .. i + spg - 1
+            i += spg
             continue
         if multi and rem > 1 and i % nb == 0 and i + rem == args.steps:
-            model.train_steps(batches[:rem], ids_tms=tms[:rem] if tms else None)   # the last `rem` steps
+            model.train_steps(rest[0], ids_tms=rest[1])       # the last `rem` steps
             i += rem
             continue
         kw = kws[i % nb]
@@ -1162,7 +1172,7 @@ def main():
                        'tables': len(rows), 'total_rows': int(sum(rows)), 'dim': args.dim, 'n_dense': 13,
                        'id_bits': args.idx_bits, 'ids': args.dist, 'seed': args.seed,
                        'id_layout': 'field-major [T][B]' if tms else 'sample-major [B][T]', 'optimizer': args.opt,
-                       'launch': ('hip graph replay, %d consecutive steps per replay' % nb if multi else
+                       'launch': ('hip graph replay, %d consecutive steps per replay (the %d resident batches in turn)' % (spg, nb) if multi else
                                   'hip graph replay, one step per replay') if use_graph else 'eager',
                        'sort': ('next batch\'s ids sorted on a side stream beside this step' if prefetch_sort
                                 else 'inside the step'),
