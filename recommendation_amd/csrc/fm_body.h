@@ -52,6 +52,17 @@ __device__ __forceinline__ void fm_fwd_body(const FmFwdArgs& a, int vblock, int 
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sq = s;
   float lin = 0.f;
   int bad = 0;
+  // What the sample needs LAST is requested first: its dense features and their weights (lane l takes feature l),
+  // its label and the bias.  Loaded where they are used, each of the two costs the sample a round trip of its own
+  // behind the rows' (the label's alone 1.2 us of a 10 us forward).
+  float d0 = 0.f, wd0 = 0.f, y0 = 0.f, bias0 = 0.f;
+  if (n_dense > 0) {  // uniform
+    const int j0 = l < n_dense ? l : 0;
+    d0 = dense[(int64_t) gid * n_dense + j0];
+    wd0 = wd[j0];
+  }
+  if (labels) y0 = labels[gid];  // uniform
+  if (bias) bias0 = bias[0];     // uniform
   // Fields in batches of UF per lane: first every id of the batch, then every row, so the
   // loads of a batch are all in flight together (two dependent round trips per batch, not
   // two per field).  A slot past T or with a bad id reads row 0 and is masked out.
@@ -102,17 +113,18 @@ __device__ __forceinline__ void fm_fwd_body(const FmFwdArgs& a, int vblock, int 
   }
   if (q == 0 && S) *reinterpret_cast<float4*>(S + (int64_t) gid * DIM + c * 4) = s;
   float pair = (q == 0) ? 0.5f * ((s.x * s.x - sq.x) + (s.y * s.y - sq.y) + (s.z * s.z - sq.z) + (s.w * s.w - sq.w)) : 0.f;
-  for (int j = l; j < n_dense; j += G) lin = fmaf(wd[j], dense[(int64_t) gid * n_dense + j], lin);
+  if (l < n_dense) lin = fmaf(wd0, d0, lin);
+  for (int j = l + G; j < n_dense; j += G) lin = fmaf(wd[j], dense[(int64_t) gid * n_dense + j], lin);
   float tot = pair + lin;
 #pragma unroll
   for (int o = 1; o < G; o <<= 1) tot += __shfl_xor(tot, o, 64);
 #pragma unroll
   for (int o = 1; o < G; o <<= 1) bad |= __shfl_xor(bad, o, 64);
   if (l == 0) {
-    const float z = tot + (bias ? bias[0] : 0.f);
+    const float z = tot + bias0;
     if (logit) logit[gid] = z;
     if (labels) {
-      const float y = labels[gid];
+      const float y = y0;
       const float az = fabsf(z);
       const float e = expf(-az);
       if (loss_rows) loss_rows[gid] = fmaxf(z, 0.f) - z * y + log1pf(e);
