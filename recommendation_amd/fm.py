@@ -61,6 +61,7 @@ class FactorizationMachine(object):
         self._side = None
         self._prefetched = None                # (address, B, dtype) of the ids whose sort the last step left behind
         self._cur = 0                          # which of the two plans of a buffer set holds it
+        self._multi_memo = None                # the last train_steps call: (lists, length, end addresses, graph)
         self.fused = True                      # set False to run the step as five separate launches
         self._fused_max = ops.fm_fwd_sort_max_batch()
         # beyond this many samples a table is sorted by several workgroups that each walk all its ids: only with the
@@ -261,30 +262,42 @@ class FactorizationMachine(object):
         that gap once per replay instead of once per step.  Same launches in the same order as calling
         ``train_step`` on each batch: the same bits.  Returns the steps' mean losses as one tensor."""
         K = len(batches)
-        shapes = set((tuple(b[0].shape), b[0].dtype) for b in batches)
-        if len(shapes) != 1:
-            raise ops.MiError("train_steps: the batches of one replay must share a shape")
+        # The host's share of a replay is kept short (the device idles while it runs): a list object that was passed
+        # before, with the same length and the same first and last id tensors, is taken to hold the same buffers
+        # (pass a NEW list after replacing a batch in the middle of one).
+        memo = self._multi_memo
+        if memo is not None and memo[0] is batches and memo[1] is ids_tms and memo[2] == K and \
+                memo[3] == (batches[0][0].data_ptr(), batches[K - 1][0].data_ptr()):
+            ent = memo[4]
+        else:
+            shapes = set((tuple(b[0].shape), b[0].dtype) for b in batches)
+            if len(shapes) != 1:
+                raise ops.MiError("train_steps: the batches of one replay must share a shape")
+            key = ('multi',) + tuple((b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr()) for b in batches) + \
+                  tuple(t.data_ptr() if t is not None else 0 for t in (ids_tms or [None] * K))
+            ent = self._graphs.get(key)
+            if ent is None:
+                self._buffers(batches[0][0])
+                if self._side is None:
+                    self._side = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+                losses = torch.zeros((K,), dtype=torch.float32, device=self.device)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                keep = self.loss
+                with torch.cuda.graph(g):
+                    for j, (ids, dense, labels) in enumerate(batches):
+                        self.loss = losses[j:j + 1]
+                        self._step_body(ids, dense, labels, streams=self._side, ids_tm=ids_tms[j] if ids_tms else None)
+                    keep.copy_(losses[K - 1:K])   # the model's own loss word, inside the graph: no launch behind the replay
+                self.loss = keep
+                ent = self._graphs[key] = (g, losses, keep)
+            self._multi_memo = (batches, ids_tms, K, (batches[0][0].data_ptr(), batches[K - 1][0].data_ptr()), ent)
         self._buffers(batches[0][0])
         self._prefetched = None
-        key = ('multi',) + tuple((b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr()) for b in batches) + \
-              tuple(t.data_ptr() if t is not None else 0 for t in (ids_tms or [None] * K))
-        ent = self._graphs.get(key)
-        if ent is None:
-            if self._side is None:
-                self._side = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
-            losses = torch.zeros((K,), dtype=torch.float32, device=self.device)
-            torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            keep = self.loss
-            with torch.cuda.graph(g):
-                for j, (ids, dense, labels) in enumerate(batches):
-                    self.loss = losses[j:j + 1]
-                    self._step_body(ids, dense, labels, streams=self._side, ids_tm=ids_tms[j] if ids_tms else None)
-            self.loss = keep
-            ent = self._graphs[key] = (g, losses)
-        g, losses = ent
+        g, losses, keep = ent
         g.replay()
-        self.loss.copy_(losses[K - 1:K])
+        if self.loss is not keep:   # (another shape's buffer set was current when this graph was captured)
+            self.loss.copy_(losses[K - 1:K])
         self.steps += K
         if check_ids:
             ops.check_error_word(self.err, "FM ids")
