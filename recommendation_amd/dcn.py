@@ -97,6 +97,7 @@ class DCNv2(object):
         self.sched = torch.tensor([0.0, 1.0, 1.0, 0.0], **f32)
         self.err = ops.new_error_word(self.device)
         self.steps = 0
+        self._graphs = {}
         self._B = None
 
     # -- parameters ---------------------------------------------------------------------------
@@ -249,8 +250,32 @@ class DCNv2(object):
         ops.colsum_bf16(dY, self.vec_slices, part, N=n)
         self._apply(p, self.vec_slices, n, n)
 
-    def train_step(self, ids, dense, labels, check_ids=False, pooled=None):
-        """Forward, backward and every optimizer update; returns the mean loss (1-element tensor)."""
+    def train_step(self, ids, dense, labels, check_ids=False, pooled=None, graph=False):
+        """Forward, backward and every optimizer update; returns the mean loss (1-element tensor).
+        ``graph=True`` replays a HIP graph of the step captured on first use for these input buffers (they must stay
+        at the same addresses; their contents may change): the step's ~70 launches are one chain on one stream, so a
+        replay only drops the gaps between them - the same launches, the same bits."""
+        if graph:
+            B = ids.shape[0]
+            key = (ids.data_ptr(), dense.data_ptr() if dense is not None else 0, labels.data_ptr(), B, ids.dtype,
+                   pooled.data_ptr() if pooled is not None else 0)
+            g = self._graphs.get(key)
+            if g is None:
+                self._buffers(B, ids)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step(ids, dense, labels, pooled)
+                self._graphs[key] = g
+            g.replay()
+        else:
+            self._step(ids, dense, labels, pooled)
+        self.steps += 1
+        if check_ids:
+            ops.check_error_word(self.err, "DCN ids")
+        return self.loss
+
+    def _step(self, ids, dense, labels, pooled):
         B = ids.shape[0]
         self.forward(ids, dense, labels, pooled=pooled)
         ops.reduce_sum(self.loss_rows, 1.0 / B, out=self.loss)
@@ -291,10 +316,6 @@ class DCNv2(object):
             self.plan.prepare(ids)
             ops.bwd_apply_adagrad_rowwise(self.plan, self.dx0, self.V, self.V_acc, self.emb_lr, self.emb_eps,
                                           grad_ld=self.dp)
-        self.steps += 1
-        if check_ids:
-            ops.check_error_word(self.err, "DCN ids")
-        return self.loss
 
     # -- the step's contractions, one by one (for per-kernel timing) ----------------------------
     def contraction_calls(self):

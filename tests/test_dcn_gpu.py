@@ -133,6 +133,28 @@ def test_training_reduces_loss_like_the_oracle(dev):
     assert np.allclose(got, want, rtol=1e-2)
 
 
+def test_graph_replay_equals_eager_steps_bitwise(dev):
+    """The step replayed as a HIP graph (two alternating batches, three rounds) leaves the same bits as the eager
+    step: every dense parameter, the tables, the losses."""
+    from recommendation_amd.dcn import DCNv2
+    B, mlp = 256, (128, 64)
+    batches = []
+    for seed in (11, 12):
+        ids, dense, labels = ofm.synthetic_batch(B, ROWS, ND, seed=seed, dist='zipf')
+        batches.append([torch.from_numpy(a).to(dev) for a in (ids, dense, labels)])
+    models = []
+    for graph in (False, True):
+        m = DCNv2(ROWS, DIM, ND, dev, mlp=mlp, lr=1e-3, emb_lr=1e-2)
+        m.load_state(_state(9, mlp))
+        losses = [float(m.train_step(*batches[i % 2], graph=graph).item()) for i in range(6)]
+        models.append((m, losses))
+    (a, la), (b, lb) = models
+    assert la == lb
+    assert torch.equal(a.V, b.V) and torch.equal(a.V_acc, b.V_acc)
+    assert torch.equal(a.w_arena, b.w_arena) and torch.equal(a.m_arena, b.m_arena) and torch.equal(a.v_arena, b.v_arena)
+    assert a.steps == b.steps == 6
+
+
 def test_rejects_ragged_batch(dev):
     from recommendation_amd.dcn import DCNv2
     from recommendation_amd._lib import MiError
