@@ -207,6 +207,13 @@ def load():
         raise MiError(
             "%s not found: build it with `make -C %s` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback for the HIP path." % (LIB_PATH, os.path.join(_HERE, 'csrc')))
+    # torch ships its own copy of the HIP runtime.  If this library pulled in the system's copy first, a process that
+    # imports torch afterwards holds two runtimes and this library's launches fail with "no ROCm-capable device":
+    # with torch loaded first both bind to one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == header and library out of step

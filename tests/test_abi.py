@@ -43,3 +43,18 @@ def test_host_side_argument_checks_need_no_gpu():
     assert rc == -1 and b'key_bits' in lib.mi_last_error()
     assert lib.mi_embag_bwd_workspace_bytes(0) > 0
     assert lib.mi_embag_bwd_workspace_bytes(1 << 20) >= 2 * 4 * (1 << 20)
+
+
+@pytest.mark.gpu
+def test_binding_loaded_before_torch_still_reaches_the_device():
+    """A process that loads the binding FIRST and imports torch afterwards (build() followed by smoke() in one
+    interpreter) must still launch on the GPU: torch ships its own HIP runtime, and two runtimes in one process
+    leave this library's launches with "no ROCm-capable device"."""
+    import subprocess
+    import sys
+    code = ("from recommendation_amd import _lib; _lib.load(); import torch; from recommendation_amd import ops; "
+            "d = torch.device('cuda:0'); x = torch.arange(1024, dtype=torch.float32, device=d); "
+            "out = torch.empty((1,), dtype=torch.float32, device=d); ops.reduce_sum(x, 1.0, out=out); "
+            "assert float(out.item()) == 1023 * 1024 / 2; print('ok')")
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
