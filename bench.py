@@ -568,13 +568,15 @@ def bench_embag(args):
     toffs = ops.table_offsets(rows, dev)
     g = torch.Generator(device=dev)
     g.manual_seed(1000)
+    opt = args.opt
+    # the row-wise state is allocated BEFORE the 64 GB table: allocated behind it, the same update launch took 0.73-0.75 ms
+    # instead of 0.66-0.70 ms in 7 of 16 fresh processes (none of 16 this way round; scripts/probe_adagrad_modes.py)
+    state = torch.zeros((total,), dtype=torch.float32, device=dev) if opt == 'adagrad_rowwise' else None
     W = torch.empty((total, D), dtype=torch.float32, device=dev)
     chunk = 1 << 22
     for lo in range(0, total, chunk):
         hi = min(lo + chunk, total)
         W[lo:hi] = torch.randn((hi - lo, D), generator=g, dtype=torch.float32, device=dev).mul_(0.05)
-    opt = args.opt
-    state = torch.zeros((total,), dtype=torch.float32, device=dev) if opt == 'adagrad_rowwise' else None
     am, av = (torch.zeros_like(W), torch.zeros_like(W)) if opt == 'adam_tf' else (None, None)
     card = torch.tensor(rows, dtype=torch.float64, device=dev).view(1, T, 1)
     idt = torch.int64 if args.idx_bits == 64 else torch.int32
