@@ -338,14 +338,69 @@ __device__ __forceinline__ void table_sort_big_body(TsLds& L, int t, int part, i
       }
     }
   };
+  // The first walk of a part does both jobs at once where it can: beside counting it already moves the entries it
+  // selects, in entry order, into the wave's own sixteenth of the SECOND key / value image (which lies idle until the
+  // radix passes); when the counts of all waves are known a wave copies its entries from there to their place in the
+  // first image, and the second walk over the table's ids (a quarter of a part's time) is not made.  A wave that
+  // selects more than its sixteenth holds (ids sorted or clustered by position) says so, and the part falls back to
+  // the second walk; so does a part that had to be narrowed.
+  constexpr uint32_t STAGE_CAP = TS_MAX / TS_WAVES;
+  bool first_turn = true;
   for (;;) {  // uniform: one turn unless the part had to be narrowed
     unsigned long long cur_hi = hi;
-    uint32_t wave_first;
+    uint32_t wave_first, mine = 0;
     int m, below;
+    bool staged = false;
     for (;;) {  // uniform
       uint32_t nsel = 0, nbelow = 0;
       const uint32_t klo = (uint32_t) (cur_lo >> 17), khi = (uint32_t) (cur_hi >> 17);
       const int plo = (int) (cur_lo & 0x1FFFFull), phi = (int) (cur_hi & 0x1FFFFull);
+      bool ovf = false;
+      if (first_turn) {  // uniform
+        uint32_t* const ks = &kbuf[1][w * STAGE_CAP];
+        uint32_t* const vs = &vbuf[1][w * STAGE_CAP];
+        uint32_t srun = 0;
+        for (int r0 = w_lo; r0 < w_hi; r0 += WALK * MI_WAVE) {
+          uint32_t key[WALK];
+          load_round(r0, key);
+#pragma unroll
+          for (int g = 0; g < GROUPS; ++g) {
+            const int g0 = r0 + g * MI_WAVE * PER, g1 = g0 + MI_WAVE * PER;
+            const int e_first = g0 + lane * PER;
+            const bool plain = (g0 >= plo || g1 <= plo) && (g0 >= phi || g1 <= phi);  // uniform: no cut inside the group
+            bool sel[PER];
+            uint32_t c = 0;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+              const uint32_t kk = key[g * PER + j];
+              const uint32_t tlo = klo + ((plain ? g0 : e_first + j) < plo ? 1u : 0u);
+              const uint32_t thi = khi + ((plain ? g0 : e_first + j) < phi ? 1u : 0u);
+              sel[j] = kk - tlo < thi - tlo;  // tlo <= kk < thi (tlo <= thi; never for TS_NO_ENTRY)
+              c += sel[j] ? 1u : 0u;
+              nbelow += kk < tlo ? 1u : 0u;
+            }
+            if (__builtin_amdgcn_ballot_w64(c != 0)) {  // uniform
+              const uint32_t incl = ts_wave_scan(c);
+              const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) incl, MI_WAVE - 1);
+              if (srun + tot <= STAGE_CAP) {  // uniform
+                uint32_t d = srun + incl - c;
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                  if (sel[j]) {
+                    ks[d] = key[g * PER + j] - klo;
+                    vs[d] = (uint32_t) (e_first + j);
+                    ++d;
+                  }
+                }
+              } else {
+                ovf = true;
+              }
+              srun += tot;
+            }
+          }
+        }
+        nsel = srun;
+      } else {
       for (int r0 = w_lo; r0 < w_hi; r0 += WALK * MI_WAVE) {
         uint32_t key[WALK];
         load_round(r0, key);
@@ -369,20 +424,30 @@ __device__ __forceinline__ void table_sort_big_body(TsLds& L, int t, int part, i
         }
       }
       nsel = __builtin_amdgcn_readlane((int) ts_wave_scan(nsel), MI_WAVE - 1);
+      }
       nbelow = __builtin_amdgcn_readlane((int) ts_wave_scan(nbelow), MI_WAVE - 1);
       __syncthreads();  // (the previous turn's readers of wsel and of the key images are done)
       if (lane == 0) {
-        L.wsel[w][0] = nsel;
+        L.wsel[w][0] = nsel | (ovf ? 0x80000000u : 0u);  // (a wave's count is at most n / 16 <= 8192)
         L.wsel[w][1] = nbelow;
       }
       __syncthreads();
-      const uint32_t a_sel = lane < TS_WAVES ? L.wsel[lane][0] : 0u, a_below = lane < TS_WAVES ? L.wsel[lane][1] : 0u;
+      uint32_t a_sel = lane < TS_WAVES ? L.wsel[lane][0] : 0u;
+      const uint32_t a_below = lane < TS_WAVES ? L.wsel[lane][1] : 0u;
+      const bool any_ovf = __builtin_amdgcn_ballot_w64((a_sel >> 31) != 0u) != 0ull;
+      a_sel &= 0x7FFFFFFFu;
       const uint32_t i_sel = ts_wave_scan(a_sel), i_below = ts_wave_scan(a_below);
       wave_first = (uint32_t) __builtin_amdgcn_readlane((int) (i_sel - a_sel), w);
+      mine = (uint32_t) __builtin_amdgcn_readlane((int) a_sel, w);
       m = __builtin_amdgcn_readlane((int) i_sel, MI_WAVE - 1);
       below = __builtin_amdgcn_readlane((int) i_below, MI_WAVE - 1);
       TS_MARK(2);
-      if (m <= TS_MAX) break;
+      const bool was_first = first_turn;
+      first_turn = false;
+      if (m <= TS_MAX) {
+        staged = was_first && !any_ovf;
+        break;
+      }
       cur_hi = cur_lo + (cur_hi - cur_lo) / 2;  // order words are distinct: a range of one word holds one entry
     }
     const uint32_t key_lo = (uint32_t) (cur_lo >> 17);
@@ -392,7 +457,13 @@ __device__ __forceinline__ void table_sort_big_body(TsLds& L, int t, int part, i
     for (uint32_t v = span; v; v >>= 1) ++bits;
     uint32_t run = wave_first;
     const int plo = (int) (cur_lo & 0x1FFFFull), phi = (int) (cur_hi & 0x1FFFFull);
-    for (int r0 = w_lo; r0 < w_hi; r0 += WALK * MI_WAVE) {
+    if (staged) {  // uniform: the first walk left this wave's entries in its sixteenth of the second image
+      for (uint32_t i = (uint32_t) lane; i < mine; i += MI_WAVE) {
+        kbuf[0][wave_first + i] = kbuf[1][w * STAGE_CAP + i];
+        vbuf[0][wave_first + i] = vbuf[1][w * STAGE_CAP + i];
+      }
+    }
+    for (int r0 = w_lo; r0 < (staged ? w_lo : w_hi); r0 += WALK * MI_WAVE) {
       uint32_t key[WALK];
       load_round(r0, key);
 #pragma unroll
