@@ -260,7 +260,10 @@ class FactorizationMachine(object):
         may change).  Between two replays the device idles for the 4-5 us a graph launch costs; inside a replay a
         launch follows its predecessor at once, so a training loop that has its next few batches at hand pays
         that gap once per replay instead of once per step.  Same launches in the same order as calling
-        ``train_step`` on each batch: the same bits.  Returns the steps' mean losses as one tensor."""
+        ``train_step`` on each batch: the same bits.  Returns the steps' mean losses as one tensor.
+        Calling again with the SAME list objects (same length, same first and last id tensors) replays the graph
+        found for them last time without looking at the batches in between: build a new list when one of its
+        batches is replaced by another tensor."""
         K = len(batches)
         # The host's share of a replay is kept short (the device idles while it runs): a list object that was passed
         # before, with the same length and the same first and last id tensors, is taken to hold the same buffers
