@@ -1102,5 +1102,13 @@ def test_fm_several_steps_in_one_graph_leave_the_same_bits(dev):
         want = torch.cat([b.train_step(*bufs[j], ids_tm=tms[j]).clone() for j in range(K)])
         assert torch.equal(losses, want)
         assert torch.equal(a.loss, b.loss)
+    # a batch in the middle replaced by other tensors: NEW list objects (a list seen before is taken to hold the buffers
+    # it held then), another graph
+    other = tuple(torch.from_numpy(x).to(dev) for x in ofm.synthetic_batch(B, rows, 13, seed=999, dist='zipf'))
+    bufs2 = [bufs[0], other] + bufs[2:]
+    tms2 = [tms[0], other[0].t().contiguous()] + tms[2:]
+    losses = a.train_steps(bufs2, ids_tms=tms2).clone()
+    want = torch.cat([b.train_step(*bufs2[j], ids_tm=tms2[j]).clone() for j in range(K)])
+    assert torch.equal(losses, want) and torch.equal(a.loss, b.loss)
     assert torch.equal(a.table.rec, b.table.rec) and torch.equal(a.dp, b.dp) and torch.equal(a.sched, b.sched)
-    assert a.steps == b.steps == 3 * K
+    assert a.steps == b.steps == 4 * K
