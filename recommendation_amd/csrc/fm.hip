@@ -53,8 +53,7 @@ __global__ __launch_bounds__(TS_THREADS) void fm_fwd_sort_kernel(FmFwdArgs a, in
     if ((int) blockIdx.x < sort_blocks) {
       int t, part, np;
       if (!ts_assign(a.toffs, a.T, a.B, parts, (int) blockIdx.x, t, part, np)) return;
-      // (not the large-table body alone, SIZES = 2: the compiler then spills more in it, 76 bytes of scratch against 28)
-      table_sort_body<IDX, 0>(t, part, np, a.toffs, a.T, a.ids, 1, a.B, sentinel, sorted_rows, perm, a.ids_tm != 0);
+      table_sort_body<IDX>(t, part, np, a.toffs, a.T, a.ids, 1, a.B, sentinel, sorted_rows, perm, a.ids_tm != 0);
       return;
     }
     const int fb = (int) blockIdx.x - sort_blocks;
@@ -64,7 +63,7 @@ __global__ __launch_bounds__(TS_THREADS) void fm_fwd_sort_kernel(FmFwdArgs a, in
     if ((int) blockIdx.x >= fwd_blocks) {
       int t, part, np;
       if (!ts_assign(a.toffs, a.T, a.B, parts, (int) blockIdx.x - fwd_blocks, t, part, np)) return;
-      table_sort_body<IDX, 1>(t, part, np, a.toffs, a.T, a.ids, 1, a.B, sentinel, sorted_rows, perm, a.ids_tm != 0);
+      table_sort_body<IDX>(t, part, np, a.toffs, a.T, a.ids, 1, a.B, sentinel, sorted_rows, perm, a.ids_tm != 0);
       return;
     }
     if (sched && blockIdx.x == 0 && threadIdx.x == 0) adam_schedule_body(sched, lr, b1, b2);

@@ -524,21 +524,17 @@ __device__ __forceinline__ void table_sort_big_body(TsLds& L, int t, int part, i
 }
 
 // Part `part` of `parts` of table `t` is sorted by the calling workgroup (all TS_THREADS threads
-// take part).  SIZES: 0 = any n; 1 = the caller knows n <= TS_MAX, 2 = it knows n > TS_MAX (a kernel that only
-// ever sees one of the two carries neither the other's code nor its registers).
-template <typename IDX, int SIZES = 0>
+// take part).
+template <typename IDX>
 __device__ __forceinline__ void table_sort_body(int t, int part, int parts, const int64_t* __restrict__ toffs, int T,
                                                 const void* __restrict__ indices, int bag_len, int n,
                                                 uint32_t sentinel, uint32_t* __restrict__ sorted_rows,
                                                 uint32_t* __restrict__ perm, bool ids_tm = false) {
   __shared__ TsLds L;
-  if constexpr (SIZES != 1) {
-    if (SIZES == 2 || n > TS_MAX) {  // uniform
-      table_sort_big_body<IDX>(L, t, part, parts, toffs, T, indices, bag_len, n, sentinel, sorted_rows, perm);  // (table-major ids: the host checks)
-      return;
-    }
+  if (n > TS_MAX) {  // uniform
+    table_sort_big_body<IDX>(L, t, part, parts, toffs, T, indices, bag_len, n, sentinel, sorted_rows, perm);  // (table-major ids: the host checks)
+    return;
   }
-  if constexpr (SIZES == 2) return;
   auto& kbuf = L.kbuf;
   auto& vbuf = L.vbuf;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
