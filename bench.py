@@ -335,7 +335,31 @@ def host_fed_line(model, batches, steps, dev, resident_ms):
         graph.replay()
     torch.cuda.synchronize()
     t_pipe = (time.perf_counter() - t0) / (reps * nb)
-    cur = torch.cuda.current_stream()
+    # The same pipeline with the copy INSIDE the step: the update launch of step i also brings batch i+1 into the other
+    # buffer set (train_step(stage=...), mi_fm_bwd_apply_dense_stage) - one chain of launches, no second stream, no
+    # event.  Measured beside the side-stream pipeline and SLOWER, so it is reported, not used: the step takes 49 us,
+    # i.e. the update launch (16.5 us alone) lasts ~36 us with the copy workgroups in it - their PCIe reads take longer
+    # beside the update than the 26 us of the copy alone, and nothing of them overlaps the step's first launch.
+    # (An even number of batches, so that every replay starts at buffer set 0.)
+    t_in = None
+    if nb % 2 == 0:
+        ops.stage_from_host(dblk[0], host[0])
+        torch.cuda.synchronize()
+        graph2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph2):
+            for i in range(nb):
+                k = i % 2
+                model.train_step(shape_only, bufs[k][1], bufs[k][2], ids_tm=bufs[k][0],
+                                 stage=(dblk[k ^ 1], host[(i + 1) % nb]))
+        model.steps -= nb
+        for _ in range(2):
+            graph2.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            graph2.replay()
+        torch.cuda.synchronize()
+        t_in = (time.perf_counter() - t0) / (reps * nb)
     for j in range(4):
         ops.stage_from_host(dblk[j % 2], host[j % nb])
     torch.cuda.synchronize()
@@ -353,7 +377,12 @@ def host_fed_line(model, batches, steps, dev, resident_ms):
             'overlap': round(max(t_copy * 1e3, resident_ms) / (t_pipe * 1e3), 3),
             'how': 'pinned host memory, one block per batch copied by a kernel (mi_stage_from_host) on a side stream '
                    'into one of two device buffer sets beside the step on the other; %d steps and their copies '
-                   'replayed as one HIP graph' % nb}
+                   'replayed as one HIP graph' % nb,
+            'copy_inside_the_update_launch': None if t_in is None else {
+                'value': round(B / t_in, 1), 'ms_per_step': round(t_in * 1e3, 4),
+                'how': 'the update launch of a step also copies the next batch\'s block into the other buffer set '
+                       '(mi_fm_bwd_apply_dense_stage: copy workgroups behind the dense side\'s); one chain of launches, '
+                       'no second stream - measured, not used: slower than the side stream'}}
 
 
 def host_cores():

@@ -393,6 +393,22 @@ int mi_fm_bwd_apply_dense(const mi_bwd_plan* plan, const mi_fm_table* tab, const
                           const float* loss_rows, float* dp, float* dm, float* dv, float dense_lr_t,
                           const float* dense_lr_dev, float* loss_out, void* stream);
 
+/* mi_fm_bwd_apply_dense whose launch also brings in the NEXT batch: beside the update and the dense
+ * side, up to 64 further workgroups copy stage_bytes (a multiple of 16) from pinned host memory
+ * (stage_src_host, a host pointer the device can read: hipHostMalloc / a pinned torch tensor) to
+ * stage_dst, the device block the next step reads its ids / dense features / labels from.  The
+ * reference's loop reads its batch every step (recommendation/local_train_utils.py:34-41,60-63);
+ * this is that read, inside the step's own launch instead of on a second stream behind events.
+ * The update's results are the bits of mi_fm_bwd_apply_dense; stage_dst must not be a buffer this
+ * step still reads (keep two blocks and alternate).  Needs the plan of the one-launch update. */
+int mi_fm_bwd_apply_dense_stage(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* g,
+                                const float* S, int opt, float lr, const float* lr_dev, float beta1,
+                                float beta2, float eps, const float* dense, int n_dense,
+                                const float* loss_rows, float* dp, float* dm, float* dv,
+                                float dense_lr_t, const float* dense_lr_dev, float* loss_out,
+                                void* stage_dst, const void* stage_src_host, size_t stage_bytes,
+                                void* stream);
+
 /* tf.train.AdamOptimizer's scalar state kept on the device, as TensorFlow keeps it
  * (model_trainer.py:157): sched = {alpha_t, beta1_power, beta2_power}, initialised by the
  * caller to {0, 1, 1}.  One call = one optimizer step: both powers are multiplied by their

@@ -161,6 +161,8 @@ _SIGNATURES = {
     'mi_fm_sort_ids': (c_int, [P, c_int, P, c_int, c_int64, c_int, c_int64, P, P, P]),
     'mi_fm_bwd_apply_dense': (c_int, [POINTER(BwdPlan), POINTER(FmTable), P, P, c_int, c_float, P, c_float, c_float,
                                       c_float, P, c_int, P, P, P, P, c_float, P, P, P]),
+    'mi_fm_bwd_apply_dense_stage': (c_int, [POINTER(BwdPlan), POINTER(FmTable), P, P, c_int, c_float, P, c_float, c_float,
+                                            c_float, P, c_int, P, P, P, P, c_float, P, P, P, P, c_size_t, P]),
     'mi_parse_records': (c_int, [c_char_p, c_int64, c_int, c_int, c_int64, P, P, POINTER(c_int64), POINTER(c_int64)]),
     'mi_shard_block_ints': (c_int64, [c_int64, c_int]),
     'mi_shard_route': (c_int, [P, c_int, P, c_int, c_int64, c_int, P, P, P]),

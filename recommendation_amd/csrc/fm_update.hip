@@ -141,3 +141,37 @@ extern "C" int mi_fm_bwd_apply_dense(const mi_bwd_plan* plan, const mi_fm_table*
                            extra);
 }
 
+extern "C" int mi_fm_bwd_apply_dense_stage(const mi_bwd_plan* plan, const mi_fm_table* tab, const float* g,
+                                           const float* S, int opt, float lr, const float* lr_dev, float beta1,
+                                           float beta2, float eps, const float* dense, int n_dense,
+                                           const float* loss_rows, float* dp, float* dm, float* dv, float dense_lr_t,
+                                           const float* dense_lr_dev, float* loss_out, void* stage_dst,
+                                           const void* stage_src_host, size_t stage_bytes, void* stream) {
+  const char* who = "mi_fm_bwd_apply_dense_stage";
+  MI_REQUIRE(plan && tab, "%s: null pointer", who);
+  MI_REQUIRE(g && dp && dm && dv && n_dense >= 0 && (n_dense == 0 || dense), "%s: bad dense-side arguments", who);
+  MI_REQUIRE((loss_rows == nullptr) == (loss_out == nullptr), "%s: loss_rows and loss_out go together", who);
+  MI_REQUIRE(stage_dst && stage_src_host && stage_bytes > 0 && stage_bytes % 16 == 0 &&
+                 ((uintptr_t) stage_dst & 15) == 0 && ((uintptr_t) stage_src_host & 15) == 0,
+             "%s: the staged block needs both pointers and a size that are multiples of 16", who);
+  const int64_t B = plan->n_bags / (plan->T > 0 ? plan->T : 1);
+  MI_REQUIRE(B >= 1, "%s: empty batch", who);
+  if (plan->unique_rows) {
+    mi_set_error("%s: takes the plan of the one-launch update (no run arrays)", who);
+    return MI_ERR_UNSUPPORTED;
+  }
+  FmDenseStageExtra extra;
+  extra.dense_blocks = n_dense + 1 + (loss_rows ? 1 : 0);
+  extra.n = stage_bytes / 16;
+  const size_t want = (extra.n + (size_t) UBLOCK * 8 - 1) / ((size_t) UBLOCK * 8);
+  extra.blocks = extra.dense_blocks + (int) (want < 64 ? want : 64);
+  extra.dst = (float4*) stage_dst;
+  extra.src = (const float4*) stage_src_host;
+  extra.a.g = g; extra.a.g_ld = 1; extra.a.dense = dense; extra.a.dense_ld = n_dense; extra.a.n_dense = n_dense;
+  extra.a.B = B; extra.a.grad_out = nullptr; extra.a.loss_rows = loss_rows; extra.a.loss_ld = 1;
+  extra.a.dp = dp; extra.a.dm = dm; extra.a.dv = dv; extra.a.lr_t = dense_lr_t; extra.a.lr_dev = dense_lr_dev;
+  extra.a.b1 = beta1; extra.a.b2 = beta2; extra.a.eps = eps; extra.a.loss_out = loss_out;
+  return fm_bwd_apply_impl(who, plan, tab, g, 1, S, tab->dim, nullptr, opt, lr, lr_dev, beta1, beta2, eps, stream,
+                           extra);
+}
+

@@ -901,6 +901,38 @@ struct FmDenseExtra {
   FmDenseArgs a;
   __device__ __forceinline__ void run(int j, float* sh) const { fm_dense_body(a, j, sh); }
 };
+// The dense side of an FM step (workgroups [0, dense_blocks)) and, behind it, workgroups that copy the NEXT batch's
+// block from pinned host memory into the device buffers the next step reads (n 16-byte words; the reads cross PCIe, a
+// round trip of microseconds: eight per thread in flight).  The batch then arrives through the step's own launch -
+// no second stream, no event - while the update keeps the memory system busy.
+struct FmDenseStageExtra {
+  int blocks;
+  FmDenseArgs a;
+  int dense_blocks;
+  float4* dst;
+  const float4* src;
+  size_t n;
+  __device__ __forceinline__ void run(int j, float* sh) const {
+    if (j < dense_blocks) {  // uniform
+      fm_dense_body(a, j, sh);
+      return;
+    }
+    const size_t stride = (size_t) (blocks - dense_blocks) * UBLOCK;
+    for (size_t i = (size_t) (j - dense_blocks) * UBLOCK + threadIdx.x; i < n; i += 8 * stride) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const size_t k = i + u * stride;
+        v[u] = src[k < n ? k : i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const size_t k = i + u * stride;
+        if (k < n) dst[k] = v[u];
+      }
+    }
+  }
+};
 struct FmDenseFinalExtra {
   int blocks;  // 1
   FmDenseFinalArgs a;

@@ -154,7 +154,7 @@ class FactorizationMachine(object):
     def _fused_ok(self, B, ids_tm):
         return self.fused and (B <= self._fused_any_layout_max or (ids_tm is not None and B <= self._fused_max))
 
-    def _step_body(self, ids, dense, labels, streams=None, ids_tm=None):
+    def _step_body(self, ids, dense, labels, streams=None, ids_tm=None, stage=None):
         """The launches of one step.  With ``streams`` (two side streams, used under graph capture)
         the sort runs beside the forward - it only needs the ids - and the dense-side update beside
         the sparse one."""
@@ -170,8 +170,10 @@ class FactorizationMachine(object):
             ops.fm_bwd_apply_dense(self.plan, self.table, r['g'], r['S'], _OPT[self.opt], self.lr, self.beta1,
                                    self.beta2, self.eps, dense if self.n_dense else None, r['loss_rows'], self.dp,
                                    self.dm, self.dv, self.loss, lr_dev=self.sched if adam else None,
-                                   dense_lr_dev=self.sched)
+                                   dense_lr_dev=self.sched, stage=stage)
             return
+        if stage is not None:
+            raise ops.MiError("train_step: stage needs the two-launch step (fused, this batch size and id layout)")
         if streams:
             streams[0].wait_stream(main)
             with torch.cuda.stream(streams[0]):
@@ -198,7 +200,7 @@ class FactorizationMachine(object):
             dense_side()
 
     def train_step(self, ids, dense, labels, check_ids=False, graph=False, ids_tm=None, next_ids=None,
-                   next_ids_tm=None):
+                   next_ids_tm=None, stage=None):
         """One pass of the hot path; returns the mean loss as a 1-element device tensor.
         ``graph=True`` replays a HIP graph of the step captured on first use for these input
         buffers (the inputs must stay at the same addresses; their contents may change).
@@ -209,9 +211,14 @@ class FactorizationMachine(object):
         shape.  The sort by row needs nothing but ids, so it is taken off this step's critical path:
         the next batch is sorted on a side stream beside this step's forward and update, and the next
         call (which must pass that same tensor, contents unchanged) finds its sort done.  Results are
-        bit-identical to the step without ``next_ids``."""
+        bit-identical to the step without ``next_ids``.
+        ``stage`` = (device block, pinned host block): the step's second launch also copies the host block - the
+        NEXT batch as the caller lays it out - into the device block, which must not be one this step reads (two
+        blocks, taken in turn); eager steps only (capture them yourself for a graph), same bits."""
         self._buffers(ids)
         B = ids.shape[0]
+        if stage is not None and (graph or next_ids is not None):
+            raise ops.MiError("train_step: stage goes with the plain eager step")
         pre = next_ids is not None and self._fused_ok(B, ids_tm) and self._fused_ok(B, next_ids_tm)
         if pre:
             if tuple(next_ids.shape) != tuple(ids.shape) or next_ids.dtype != ids.dtype:
@@ -248,7 +255,7 @@ class FactorizationMachine(object):
         elif pre:
             self._step_prefetched(ids, dense, labels, cur, next_ids, next_ids_tm, sorted_now, ids_tm)
         else:
-            self._step_body(ids, dense, labels, ids_tm=ids_tm)
+            self._step_body(ids, dense, labels, ids_tm=ids_tm, stage=stage)
         self.steps += 1
         if check_ids:
             ops.check_error_word(self.err, "FM ids")

@@ -536,9 +536,21 @@ def fm_sort_ids(toffs, ids, plan, ids_tm=None):
 
 
 def fm_bwd_apply_dense(plan, table, g, S, opt, lr, beta1, beta2, eps, dense, loss_rows, dp, dm, dv, loss_out,
-                       lr_dev=None, dense_lr_t=0.0, dense_lr_dev=None):
-    """fm_bwd_apply (step size lr / lr_dev) + fm_dense_step (dense_lr_t / dense_lr_dev), one launch."""
+                       lr_dev=None, dense_lr_t=0.0, dense_lr_dev=None, stage=None):
+    """fm_bwd_apply (step size lr / lr_dev) + fm_dense_step (dense_lr_t / dense_lr_dev), one launch.
+    ``stage`` = (device block, pinned host block of the same size): the launch also copies the host block - the
+    NEXT batch - into the device block (mi_fm_bwd_apply_dense_stage)."""
     n_dense = dense.shape[1] if dense is not None else 0
+    if stage is not None:
+        dst, src = stage
+        _need_cuda(dst)
+        if src.is_cuda or not src.is_pinned() or not src.is_contiguous() or not dst.is_contiguous() or \
+                src.numel() * src.element_size() != dst.numel() * dst.element_size():
+            raise MiError("fm_bwd_apply_dense: stage takes (device block, pinned host block) of one size")
+        _lib.call('mi_fm_bwd_apply_dense_stage', plan.ref(), table.ref(), _p(g), _p(S), opt, lr, _p(lr_dev), beta1, beta2,
+                  eps, _p(dense), n_dense, _p(loss_rows), _p(dp), _p(dm), _p(dv), dense_lr_t, _p(dense_lr_dev),
+                  _p(loss_out), dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size(), _stream())
+        return
     _lib.call('mi_fm_bwd_apply_dense', plan.ref(), table.ref(), _p(g), _p(S), opt, lr, _p(lr_dev), beta1, beta2, eps,
               _p(dense), n_dense, _p(loss_rows), _p(dp), _p(dm), _p(dv), dense_lr_t, _p(dense_lr_dev), _p(loss_out),
               _stream())

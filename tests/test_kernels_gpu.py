@@ -1078,6 +1078,73 @@ def test_fm_next_batch_sort_prefetch_leaves_the_same_bits(dev, opt, tm):
         assert torch.equal(models[0].dp, m.dp) and torch.equal(models[0].sched, m.sched)
 
 
+def test_fm_step_that_brings_in_the_next_batch_leaves_the_same_bits(dev):
+    """train_step(stage=...): the second launch also copies the next batch's pinned host block (ids field-major int32 |
+    dense | labels) into the other device block.  Same records, dense parameters, schedule and losses as the step on
+    resident tensors; the device blocks hold the host blocks' bytes; eager and captured in a graph by the caller."""
+    from recommendation_amd import ops
+    from recommendation_amd.fm import FactorizationMachine
+    rows = [1460, 583, 30000, 305, 24, 3, 10, 4, 18, 15, 105, 27, 2173]
+    T, nd, B, K = len(rows), 13, 2048, 4
+    ref = ofm.State(rows, 16, nd, seed=31, opt='adam_tf')
+    a = FactorizationMachine(rows, 16, nd, device=dev, opt='adam_tf', lr=1e-2)
+    b = FactorizationMachine(rows, 16, nd, device=dev, opt='adam_tf', lr=1e-2)
+    for m in (a, b):
+        m.load_state(ref)
+    data = [ofm.synthetic_batch(B, rows, nd, seed=400 + j, dist='zipf') for j in range(K)]
+    sizes = [T * B * 4, B * nd * 4, B * 4]
+    offs = [0, -(-sizes[0] // 256) * 256]
+    offs.append(offs[1] + -(-sizes[1] // 256) * 256)
+    total = offs[2] + -(-sizes[2] // 256) * 256
+
+    def views(block):
+        return (block[offs[0]:offs[0] + sizes[0]].view(torch.int32).view(T, B),
+                block[offs[1]:offs[1] + sizes[1]].view(torch.float32).view(B, nd),
+                block[offs[2]:offs[2] + sizes[2]].view(torch.float32).view(B))
+
+    host = []
+    for ids, dense, labels in data:
+        blk = torch.zeros((total,), dtype=torch.uint8).pin_memory()
+        v = views(blk)
+        v[0].copy_(torch.from_numpy(ids.T.astype(np.int32)))
+        v[1].copy_(torch.from_numpy(dense))
+        v[2].copy_(torch.from_numpy(labels))
+        host.append(blk)
+    dblk = [torch.zeros((total,), dtype=torch.uint8, device=dev) for _ in range(2)]
+    bufs = [views(d) for d in dblk]
+    shape_only = torch.empty((B, T), dtype=torch.int32, device=dev)
+    res = [tuple(torch.from_numpy(x).to(dev) for x in (ids.astype(np.int32), dense, labels)) for ids, dense, labels in data]
+    res_tm = [r[0].t().contiguous() for r in res]
+
+    def staged_steps(first):
+        out = []
+        for i in range(first, first + K):
+            k = i % 2
+            out.append(b.train_step(shape_only, bufs[k][1], bufs[k][2], ids_tm=bufs[k][0],
+                                    stage=(dblk[k ^ 1], host[(i + 1) % K])).clone())
+        return out
+
+    ops.stage_from_host(dblk[0], host[0])
+    got = staged_steps(0)
+    want = [a.train_step(*res[i % K], ids_tm=res_tm[i % K]).clone() for i in range(K)]
+    assert torch.equal(torch.cat(got), torch.cat(want))
+    # after K (even) steps block 0 holds batch 0 again and block 1 batch K - 1
+    assert torch.equal(dblk[0].cpu(), host[0]) and torch.equal(dblk[1].cpu(), host[K - 1])
+    # the same steps captured by the caller as one graph (one chain of launches, no second stream)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        losses = torch.cat(staged_steps(0))
+    b.steps -= K                       # (capture does not run the steps)
+    g.replay()
+    b.steps += K
+    want = torch.cat([a.train_step(*res[i % K], ids_tm=res_tm[i % K]).clone() for i in range(K)])
+    assert torch.equal(losses, want)
+    assert torch.equal(a.table.rec, b.table.rec) and torch.equal(a.dp, b.dp) and torch.equal(a.sched, b.sched)
+    with pytest.raises(ops.MiError):
+        b.train_step(shape_only, bufs[0][1], bufs[0][2], ids_tm=bufs[0][0], stage=(dblk[1], host[0].clone()))   # not pinned
+
+
 def test_fm_several_steps_in_one_graph_leave_the_same_bits(dev):
     """train_steps (one HIP graph of consecutive steps) against train_step per batch: same losses, records, dense
     parameters and schedule, bit for bit, also when the replay is repeated with new contents in the same buffers."""
